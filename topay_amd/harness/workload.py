@@ -1,0 +1,163 @@
+"""ctypes front-end of the synthetic workload generator (libtopay_workload.so).
+
+Builds the BASELINE.json configurations: seeded "tables"/"cuboids" worlds with their 2-D/3-D ESDF,
+start/goal scenarios, and front-end stand-in init paths (ragged P x 10 states per candidate).
+Harness only: runs on the CPU, once per map/scenario, outside every timed region.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+TABLES, CUBOIDS = 0, 1
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libtopay_workload.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.wl_world_create.restype = C.c_void_p
+        L.wl_world_create.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                      c_dp, C.c_int]
+        L.wl_world_esdf2d.restype = c_dp
+        L.wl_world_esdf3d.restype = c_dp
+        L.wl_world_esdf2d.argtypes = [C.c_void_p]
+        L.wl_world_esdf3d.argtypes = [C.c_void_p]
+        L.wl_world_destroy.argtypes = [C.c_void_p]
+        L.wl_world_desc.argtypes = [C.c_void_p, c_ip, c_dp, c_dp, c_dp, c_dp]
+        L.wl_sample_start_goal_xy.argtypes = [C.c_uint64, C.c_double, c_dp, c_dp]
+        L.wl_sample_arm.argtypes = [C.c_void_p, C.c_uint64, c_dp]
+        L.wl_sample_scenario.argtypes = [C.c_void_p, C.c_uint64, c_dp, c_dp]
+        L.wl_whole_body_collision.argtypes = [C.c_void_p, c_dp]
+        L.wl_init_paths.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, C.c_uint64, c_dp, C.c_int, c_ip]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+class World:
+    def __init__(self, kind, seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, keepouts=None, nthreads=0):
+        L = lib()
+        ko = np.zeros((0, 2)) if keepouts is None else np.ascontiguousarray(keepouts, dtype=np.float64).reshape(-1, 2)
+        self.h = C.c_void_p(L.wl_world_create(kind, seed, size_xy, size_z, res, cloud_res, ko.shape[0], _dp(ko), nthreads))
+        self.kind = kind
+        self.size_xy = size_xy
+        dims = np.zeros(3, dtype=np.int32)
+        origin = np.zeros(3)
+        mn = np.zeros(3)
+        mx = np.zeros(3)
+        r = C.c_double(0)
+        L.wl_world_desc(self.h, dims.ctypes.data_as(c_ip), _dp(origin), C.byref(r), _dp(mn), _dp(mx))
+        self.dims, self.origin, self.res, self.min_b, self.max_b = dims, origin, r.value, mn, mx
+        n2 = int(dims[0]) * int(dims[1])
+        n3 = n2 * int(dims[2])
+        self.esdf2d = np.ctypeslib.as_array(L.wl_world_esdf2d(self.h), shape=(n2,))
+        self.esdf3d = np.ctypeslib.as_array(L.wl_world_esdf3d(self.h), shape=(n3,))
+
+    def close(self):
+        if self.h:
+            lib().wl_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sample_scenario(self, seed):
+        s = np.zeros(10)
+        g = np.zeros(10)
+        ok = lib().wl_sample_scenario(self.h, seed, _dp(s), _dp(g))
+        return bool(ok), s, g
+
+    def sample_arm(self, seed, state):
+        st = np.ascontiguousarray(state, dtype=np.float64).copy()
+        ok = lib().wl_sample_arm(self.h, seed, _dp(st))
+        return bool(ok), st
+
+    def collision(self, state):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        return bool(lib().wl_whole_body_collision(self.h, _dp(st)))
+
+    def init_paths(self, start, goal, n_cand, seed, max_states=20000):
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        goal = np.ascontiguousarray(goal, dtype=np.float64)
+        out = np.zeros(max_states * 10)
+        lens = np.zeros(n_cand, dtype=np.int32)
+        made = lib().wl_init_paths(self.h, _dp(start), _dp(goal), n_cand, seed, _dp(out), max_states,
+                                   lens.ctypes.data_as(c_ip))
+        if made < 0:
+            raise RuntimeError("init path buffer too small")
+        lens = lens[:made]
+        tot = int(lens.sum())
+        return lens.copy(), out[: tot * 10].reshape(tot, 10).copy()
+
+
+def sample_start_goal_xy(seed, size_xy=20.0):
+    s = np.zeros(3)
+    g = np.zeros(3)
+    lib().wl_sample_start_goal_xy(seed, size_xy, _dp(s), _dp(g))
+    return s, g
+
+
+def tables_scenario(scenario_id, n_cand, base_seed=42, **world_kw):
+    """Reference flow for the 'tables' scene (planner.cpp:498-548): sample start/goal, build the map with 1x1 m
+    keep-outs at both, then rejection-sample the arm joints.  Returns (world, start, goal, lens, paths)."""
+    seed = base_seed + scenario_id
+    for attempt in range(50):
+        s3, g3 = sample_start_goal_xy(seed * 1000 + attempt, world_kw.get("size_xy", 20.0))
+        w = World(TABLES, seed=seed * 1000 + attempt, keepouts=[s3[:2], g3[:2]], **world_kw)
+        start = np.zeros(10)
+        goal = np.zeros(10)
+        start[:3] = s3
+        goal[:3] = g3
+        ok1, goal = w.sample_arm(seed * 7919 + 2 * attempt, goal)
+        ok2, start = w.sample_arm(seed * 7919 + 2 * attempt + 1, start)
+        if not (ok1 and ok2):
+            w.close()
+            continue
+        lens, paths = w.init_paths(start, goal, n_cand, seed * 104729 + attempt)
+        if len(lens) == 0:
+            w.close()
+            continue
+        return w, start, goal, lens, paths
+    raise RuntimeError("could not build a tables scenario")
+
+
+def cuboids_batch(n_scenarios, n_cand, map_seed=42, base_seed=42, first_scenario=0, **world_kw):
+    """n_scenarios random start/goal pairs x n_cand candidates on ONE cuboids map (BASELINE config 3).
+    Returns (world, lens, paths, scenario_of_traj)."""
+    w = World(CUBOIDS, seed=map_seed, **world_kw)
+    all_lens, all_paths, scen = [], [], []
+    sid = first_scenario
+    made = 0
+    while made < n_scenarios:
+        ok, s, g = w.sample_scenario(base_seed + sid)
+        sid += 1
+        if not ok:
+            continue
+        lens, paths = w.init_paths(s, g, n_cand, (base_seed + sid) * 104729)
+        if len(lens) < n_cand:
+            continue
+        all_lens.append(lens)
+        all_paths.append(paths)
+        scen += [made] * len(lens)
+        made += 1
+    return w, np.concatenate(all_lens), np.concatenate(all_paths), np.asarray(scen, dtype=np.int32)
