@@ -1,0 +1,209 @@
+/*
+ * topay.h — C-ABI of the MI355X-native batched (s,theta) trajectory optimizer.
+ *
+ * Drop-in boundary for ONE hot path of TopAY-Planner/TopAY: `MomaTrajOpt::optimizeTraj`
+ * (reference: src/planner/src/moma_traj_opt.cpp:142-498) and what it calls per L-BFGS
+ * iteration.  The reference exposes an in-process C++ class, one instance per candidate
+ * thread (src/planner/include/planner/moma_traj_opt.h:613-674); this ABI is the same surface,
+ * batch-first: one context optimises `batch` independent candidate trajectories at once,
+ * one 64-lane wavefront per trajectory, on one GPU.
+ *
+ *   reference member                                   replaced by
+ *   -------------------------------------------------  ------------------------------------
+ *   MomaTrajOpt(GridMap::Ptr)        moma_traj_opt.h:651   topay_create + topay_set_map
+ *   init(ros::NodeHandle&)           moma_traj_opt.h:845   topay_default_params / topay_create
+ *   optimizeTraj(...) lines 146-357  moma_traj_opt.cpp     topay_set_init_traj
+ *   optimizeTraj(...) lines 359-497  moma_traj_opt.cpp     topay_optimize
+ *   getTraj(), traj_cost             moma_traj_opt.h:943   topay_get_result
+ *   first/secondStageCostCallback    moma_traj_opt.cpp:817,885   topay_eval (test hook)
+ *   printConstraintsSituations       moma_traj_opt.h:1052  topay_check_feasible
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types, never throws.  Every call
+ * returns a topay_status (0 = ok).  A context is single-caller (like one MomaTrajOpt); several
+ * contexts may coexist (one per GPU / process).  All host buffers are caller-owned and copied;
+ * the context owns its device memory.  Arithmetic is IEEE double throughout.
+ */
+#ifndef TOPAY_H
+#define TOPAY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int topay_status;
+enum {
+  TOPAY_OK = 0,
+  TOPAY_ERR_INVALID_ARG = -1,
+  TOPAY_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error; see topay_last_error() */
+  TOPAY_ERR_NO_MAP = -3,
+  TOPAY_ERR_NO_TRAJ = -4,
+  TOPAY_ERR_TOO_MANY_PIECES = -5,
+  TOPAY_ERR_UNSUPPORTED = -6
+};
+
+/* Per-trajectory solver status (reported by topay_get_result / topay_get_stats).  Values >= -1024
+ * are the reference's L-BFGS codes (src/planner/include/utils/lbfgs.hpp:135-184). */
+enum {
+  TOPAY_LBFGS_CONVERGENCE = 0,
+  TOPAY_LBFGS_STOP = 1,
+  TOPAY_LBFGS_CANCELED = 2,
+  TOPAY_LBFGSERR_INVALID_FUNCVAL = -1012,
+  TOPAY_LBFGSERR_MINIMUMSTEP = -1011,
+  TOPAY_LBFGSERR_MAXIMUMSTEP = -1010,
+  TOPAY_LBFGSERR_MAXIMUMLINESEARCH = -1009,
+  TOPAY_LBFGSERR_MAXIMUMITERATION = -1008,
+  TOPAY_LBFGSERR_WIDTHTOOSMALL = -1007,
+  TOPAY_LBFGSERR_INVALIDPARAMETERS = -1006,
+  TOPAY_LBFGSERR_INCREASEGRADIENT = -1005
+};
+
+/* L-BFGS parameter block — mirrors lbfgs::lbfgs_parameter_t (lbfgs.hpp:15-129). */
+typedef struct {
+  int mem_size;
+  int past;
+  int max_iterations;
+  int max_linesearch;
+  double g_epsilon;
+  double delta;
+  double min_step;
+  double max_step;
+  double f_dec_coeff;
+  double s_curv_coeff;
+  double cautious_factor;
+  double machine_prec;
+} topay_lbfgs_params_t;
+
+/* Optimizer parameters — mirror MomaTrajOptParam (moma_traj_opt.h:441-564) with the values of
+ * src/planner/params/optimizer.yaml as defaults, plus the MomaParam constants the path reads
+ * (src/simulator/fake_moma/include/fake_moma/moma_param.h:36-126). */
+typedef struct {
+  int int_K;            /* Simpson panels per piece; this build supports 12 only */
+  int min_piece_num;
+  double relu_mu;
+  double sample_interval;
+  double energy_weights[9];
+  /* first stage */
+  double s1_time_weight, s1_moment_weight, s1_acc_weight, s1_domega_weight, s1_path_pos_weight;
+  int s1_normal_past, s1_shot_path_past;
+  double s1_shot_path_horizon;
+  topay_lbfgs_params_t s1_lbfgs;
+  /* second stage */
+  double s2_time_weight, s2_moment_weight, s2_acc_weight, s2_domega_weight;
+  double s2_collision_weight, s2_mani_colli_weight, s2_self_colli_weight;
+  double s2_mani_pos_weight, s2_mani_vel_weight, s2_mani_acc_weight, s2_mean_time_weight;
+  topay_lbfgs_params_t s2_lbfgs;
+  /* ALM on the end-point constraint (only entries [0],[1] of the reference's vectors are used) */
+  double alm_init_lambda[2], alm_init_rho[2], alm_rho_max[2], alm_gamma[2];
+  double alm_tolerance;
+  /* Deterministic replacement of the reference's 1.0 s wall-clock cap on the ALM loop
+   * (moma_traj_opt.cpp:403-407): maximum number of outer iterations. */
+  int alm_max_outer;
+  /* robot (MomaParam) */
+  double chassis_height, chassis_colli_radius;
+  double max_v, max_a, max_w, max_dw;
+  double colli_length[8];
+  double colli_points[16];
+  double colli_point_radius[16];
+  double joint_pos_limit_max[7];
+  double joint_vel_limit[7];
+  double joint_acc_limit[7];
+  double relative_R[9]; /* row-major */
+  double relative_t[3];
+} topay_params_t;
+
+/* ESDF description — GridMap (src/map/include/map/grid_map.h) dense buffers:
+ *   esdf2d[x*dims[1] + y]                        (grid_map.h:798-806)
+ *   esdf3d[x*dims[1]*dims[2] + y*dims[2] + z]    (grid_map.h:808-816) */
+typedef struct {
+  double origin[3];
+  double resolution;
+  int dims[3];
+  double min_boundary[3];
+  double max_boundary[3];
+} topay_map_desc_t;
+
+typedef struct topay_ctx topay_ctx;
+
+/* Fill `p` with the reference defaults (optimizer.yaml + MomaParam). */
+topay_status topay_default_params(topay_params_t* p);
+
+/* Create a context on HIP device `device` (use LOCAL_RANK for one process per GPU). */
+topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out);
+void topay_destroy(topay_ctx* ctx);
+const char* topay_last_error(void);
+
+/* Upload a map; the context keeps a device copy.  Up to TOPAY_MAX_MAPS maps may be resident (the
+ * reference's benchmark loop uses a fresh map per episode); `map_id` selects the slot (0 for the
+ * single-map case). */
+#define TOPAY_MAX_MAPS 4096
+topay_status topay_set_map(topay_ctx* ctx, int map_id, const topay_map_desc_t* desc, const double* esdf2d,
+                           const double* esdf3d);
+
+/* == optimizeTraj lines 146-357 for every batch member.
+ *   path_len[b]      number of 10-d states of candidate b
+ *   init_paths       ragged, sum(path_len) x 10, row-major (x, y, theta, q1..q7)
+ *   boundary_vel/acc batch x 20, each a 10 x 2 column-major matrix as in the reference
+ *                    (row 0 = v, row 1 = omega, rows 3-9 = joints; col 0 = start, col 1 = end); NULL = zeros
+ *   map_ids          map slot per candidate, NULL = all slot 0
+ * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace. */
+topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len, const double* init_paths,
+                                 const double* boundary_vel, const double* boundary_acc, const int* map_ids);
+
+/* Re-run the init kernel from the resident raw paths (restores x0 so the same batch can be
+ * optimised again; used by bench.py so every timed step starts from HBM-resident inputs). */
+topay_status topay_reset(topay_ctx* ctx);
+
+/* == optimizeTraj lines 359-497 for every batch member (stage-1 L-BFGS, stage-2 ALM loop). */
+topay_status topay_optimize(topay_ctx* ctx);
+
+/* Batch-level results after topay_optimize: success[b] (0/1), cost[b] (traj_cost), n_pieces[b].
+ * Any pointer may be NULL. */
+topay_status topay_get_batch(topay_ctx* ctx, int* success, double* cost, int* n_pieces);
+
+/* getTraj() of candidate i: durations[N]; coeffs[N][9][6] highest order first (minco.hpp:908-921);
+ * knots_xy[(N+1)][2] Simpson-integrated piece end points.  Any output pointer may be NULL. */
+topay_status topay_get_result(topay_ctx* ctx, int i, int* success, double* cost, int* n_pieces, double* durations,
+                              double* coeffs, double* knots_xy);
+
+/* Per-candidate solver counters, 8 ints each:
+ * {stage1_ret, stage1_iters, stage1_evals, stage2_last_ret, stage2_iters, stage2_evals, alm_outer, sum_bound}
+ * sum_bound = sum over stage-2 iterations of the two-loop history length (roofline accounting). */
+topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
+
+/* Number of decision variables of candidate i (n = 10N - 8) and the packed vector
+ * x = [tau(N) | theta(N-1) | s(N) | Vq(7 x (N-1), column = knot)] (moma_traj_opt.cpp:324-344). */
+topay_status topay_get_x(topay_ctx* ctx, int i, int* n, double* x);
+
+/* Test hook == first/secondStageCostCallback (moma_traj_opt.cpp:817-955): evaluate stage `stage`
+ * (1 or 2) of candidate i at x with ALM state (lambda, rho); returns f, g[n] and, for stage 2,
+ * final_xy_error[2] (NULL allowed). */
+topay_status topay_eval(topay_ctx* ctx, int stage, int i, const double* x, const double* alm_lambda,
+                        const double* alm_rho, double* f, double* g, double* final_xy_error);
+
+/* Batched form of the hook over candidates [0, batch): x is batch x nmax (row stride nmax from
+ * topay_get_nmax), g likewise; used by bench.py to time the cost/gradient kernel on its own. */
+topay_status topay_eval_batch(topay_ctx* ctx, int stage, int repeats, double* f /* batch */);
+topay_status topay_get_nmax(topay_ctx* ctx, int* nmax, int* Nmax);
+
+/* == printConstraintsSituations (moma_traj_opt.h:1052-1204) for every candidate: feasible[b] 0/1. */
+topay_status topay_check_feasible(topay_ctx* ctx, int* feasible);
+
+/* Debug / parity tooling: record the cost f of every evaluation made by the next topay_optimize
+ * (at most `cap` per candidate, 0 switches it off); topay_get_trace copies candidate i's `cap` values. */
+topay_status topay_set_trace(topay_ctx* ctx, int cap);
+topay_status topay_get_trace(topay_ctx* ctx, int i, double* out);
+
+/* Test hook for the deterministic elementary functions of the solver (topay_amd/csrc/topay_math.h):
+ * out[4i..] = sin(a_i), cos(a_i), atan2(a_i, b_i), sqrt(|a_i|)/(1+|b_i|). */
+topay_status topay_test_math(topay_ctx* ctx, int n, const double* a, const double* b, double* out4n);
+
+/* Device time (HIP events on the context's stream) of the last topay_optimize / topay_eval_batch
+ * solve kernel(s), in milliseconds, and the number of launches it covered. */
+topay_status topay_last_kernel_ms(topay_ctx* ctx, double* ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPAY_H */

@@ -151,6 +151,12 @@ class Oracle:
     def optimize(self):
         return bool(self.L.orc_optimize(self.h))
 
+    def optimize_trace(self, cap=100000):
+        tr = np.zeros(cap)
+        ok = C.c_int(0)
+        n = self.L.orc_optimize_trace(self.h, _dp(tr), cap, C.byref(ok))
+        return bool(ok.value), tr[:min(n, cap)]
+
     def stats(self):
         s = np.zeros(8, dtype=np.int32)
         self.L.orc_get_stats(self.h, _ip(s))

@@ -119,6 +119,17 @@ void orc_get_coeffs(void* hh, double* c, double* T) {
 }
 
 int orc_optimize(void* hh) { return ((OracleHandle*)hh)->opt.optimize() ? 1 : 0; }
+// optimize with a trace of f at every evaluation; returns number of evaluations recorded (<= cap)
+int orc_optimize_trace(void* hh, double* trace, int cap, int* success) {
+  TrajOpt& o = ((OracleHandle*)hh)->opt;
+  o.trace.clear();
+  o.trace_on = true;
+  *success = o.optimize() ? 1 : 0;
+  o.trace_on = false;
+  int n = (int)std::min<size_t>(o.trace.size(), (size_t)cap);
+  std::memcpy(trace, o.trace.data(), n * sizeof(double));
+  return (int)o.trace.size();
+}
 
 void orc_get_stats(void* hh, int s[8]) {
   const SolveStats& st = ((OracleHandle*)hh)->opt.stats;

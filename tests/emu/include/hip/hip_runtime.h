@@ -1,0 +1,250 @@
+// ============================================================================
+// TEST INFRASTRUCTURE — CPU wave emulator for the HIP kernel sources.
+//
+// Compiling topay_amd/csrc/*.hip with `g++ -x c++ -I tests/emu/include` picks up THIS file
+// instead of the real <hip/hip_runtime.h>.  It runs each workgroup's lanes as ucontext fibers
+// on one OS thread so the unmodified kernel source (wave-uniform collectives only) can be
+// checked against the oracle in the `-m "not gpu"` suite and under ASan/UBSan.
+//
+// It is NOT a fallback: the product (topay_amd/api.py) loads only libtopay_hip.so built by hipcc
+// and fails loudly when that is missing.  Nothing under topay_amd/ references this directory.
+//
+// Rules the kernels follow so that emulation is faithful: __syncthreads / __shfl* / __ballot /
+// readlane are only executed in wave-uniform control flow (also required for defined behaviour
+// on the GPU for barriers).
+// ============================================================================
+#pragma once
+#include <ucontext.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <functional>
+#include <vector>
+
+#define TOPAY_CPU_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+namespace hip_emu {
+struct Lane {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+};
+struct State {
+  uint3_emu tid{0, 0, 0}, bid{0, 0, 0};
+  dim3 bdim, gdim;
+  std::vector<Lane> lanes;
+  int cur = 0;
+  ucontext_t sched;
+  // exchange buffers for collectives: 2 phases x lanes x 16 bytes
+  std::vector<unsigned char> xbuf;
+  std::vector<int> phase;  // per lane
+  unsigned char* dyn_smem = nullptr;
+  std::function<void()> body;
+  long barriers = 0;
+};
+inline State& S() {
+  static State s;
+  return s;
+}
+inline void lane_entry() {
+  State& s = S();
+  s.body();
+  s.lanes[s.cur].done = true;
+  swapcontext(&s.lanes[s.cur].ctx, &s.sched);
+}
+inline void barrier() {
+  State& s = S();
+  s.barriers++;
+  int me = s.cur;
+  swapcontext(&s.lanes[me].ctx, &s.sched);
+  // resumed: restore ids (scheduler sets cur/tid before switching in)
+}
+inline void run_block(unsigned bx, size_t shmem_bytes, const std::function<void()>& body) {
+  State& s = S();
+  const int nl = (int)(s.bdim.x * s.bdim.y * s.bdim.z);
+  s.bid = {bx, 0, 0};
+  s.body = body;
+  static const size_t STK = 1 << 20;
+  if ((int)s.lanes.size() < nl) s.lanes.resize(nl);
+  s.xbuf.assign((size_t)2 * nl * 16, 0);
+  s.phase.assign(nl, 0);
+  std::vector<unsigned char> smem(shmem_bytes + 64, 0);
+  s.dyn_smem = smem.data();
+  for (int l = 0; l < nl; l++) {
+    Lane& L = s.lanes[l];
+    if (!L.stack) L.stack = (char*)malloc(STK);
+    L.done = false;
+    getcontext(&L.ctx);
+    L.ctx.uc_stack.ss_sp = L.stack;
+    L.ctx.uc_stack.ss_size = STK;
+    L.ctx.uc_link = &s.sched;
+    makecontext(&L.ctx, (void (*)())lane_entry, 0);
+  }
+  int remaining = nl;
+  while (remaining > 0) {
+    int finished_this_sweep = 0, ran = 0;
+    for (int l = 0; l < nl; l++) {
+      if (s.lanes[l].done) continue;
+      s.cur = l;
+      s.tid = {(unsigned)l % s.bdim.x, ((unsigned)l / s.bdim.x) % s.bdim.y, (unsigned)l / (s.bdim.x * s.bdim.y)};
+      swapcontext(&s.sched, &s.lanes[l].ctx);
+      ran++;
+      if (s.lanes[l].done) finished_this_sweep++;
+    }
+    remaining -= finished_this_sweep;
+    if (finished_this_sweep != 0 && finished_this_sweep != ran) {
+      fprintf(stderr, "[hip_emu] non-uniform barrier/exit in block %u (%d of %d lanes exited)\n", bx,
+              finished_this_sweep, ran);
+      abort();
+    }
+  }
+}
+template <typename T>
+inline T exchange(T v, int src, bool valid_src = true) {
+  static_assert(sizeof(T) <= 16, "exchange payload");
+  State& s = S();
+  const int nl = (int)s.lanes.size();
+  (void)nl;
+  int me = s.cur;
+  int ph = s.phase[me];
+  s.phase[me] ^= 1;
+  const int lanes = (int)(s.bdim.x * s.bdim.y * s.bdim.z);
+  unsigned char* base = s.xbuf.data() + (size_t)ph * lanes * 16;
+  memcpy(base + (size_t)me * 16, &v, sizeof(T));
+  barrier();
+  T r = v;
+  if (valid_src && src >= 0 && src < lanes) memcpy(&r, base + (size_t)src * 16, sizeof(T));
+  return r;
+}
+}  // namespace hip_emu
+
+#define threadIdx (hip_emu::S().tid)
+#define blockIdx (hip_emu::S().bid)
+#define blockDim (hip_emu::S().bdim)
+#define gridDim (hip_emu::S().gdim)
+#define warpSize 64
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hip_emu::S().dyn_smem;
+
+inline void __syncthreads() { hip_emu::barrier(); }
+inline int __lane_id_emu() { return (int)(hip_emu::S().cur % 64); }
+
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  int me = hip_emu::S().cur;
+  int base = me & ~(width - 1);
+  return hip_emu::exchange(v, base + (src & (width - 1)));
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  int me = hip_emu::S().cur;
+  return hip_emu::exchange(v, me ^ mask);
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  int me = hip_emu::S().cur;
+  int lane = me & (width - 1);
+  return hip_emu::exchange(v, me - (int)delta, lane >= (int)delta);
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  int me = hip_emu::S().cur;
+  int lane = me & (width - 1);
+  return hip_emu::exchange(v, me + (int)delta, lane + (int)delta < width);
+}
+inline unsigned long long __ballot(int pred) {
+  // gather predicates of the 64 lanes of this wave
+  int me = hip_emu::S().cur;
+  int wbase = me & ~63;
+  unsigned long long bits = 0;
+  // one exchange round: everybody publishes, then reads all 64
+  hip_emu::State& s = hip_emu::S();
+  int ph = s.phase[me];
+  s.phase[me] ^= 1;
+  const int lanes = (int)(s.bdim.x * s.bdim.y * s.bdim.z);
+  unsigned char* base = s.xbuf.data() + (size_t)ph * lanes * 16;
+  int p = pred ? 1 : 0;
+  memcpy(base + (size_t)me * 16, &p, sizeof(int));
+  hip_emu::barrier();
+  for (int l = 0; l < 64 && wbase + l < lanes; l++) {
+    int q;
+    memcpy(&q, base + (size_t)(wbase + l) * 16, sizeof(int));
+    if (q) bits |= (1ull << l);
+  }
+  return bits;
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) {
+  int lanes = (int)(hip_emu::S().bdim.x);
+  unsigned long long full = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1);
+  return (__ballot(pred) & full) == full;
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return hip_emu::exchange(v, hip_emu::S().cur & ~63); }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hip_emu::exchange(v, (hip_emu::S().cur & ~63) + lane); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+using std::isinf;
+using std::isnan;
+using std::max;
+using std::min;
+
+// ---- host runtime shims --------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct hipEvent_emu { std::chrono::steady_clock::time_point t; };
+typedef hipEvent_emu* hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline const char* hipGetErrorString(hipError_t) { return "hip_emu"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)calloc(n ? n : 1, 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu(); return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return 0;
+}
+template <typename F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return 0; }
+
+template <typename K, typename... Args>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  hip_emu::State& s = hip_emu::S();
+  s.bdim = block;
+  s.gdim = grid;
+  for (unsigned b = 0; b < grid.x; b++) hip_emu::run_block(b, shmem, [&]() { kernel(args...); });
+}

@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's `MomaTrajOpt` surface over the C-ABI (include/topay.h).
+
+The reference interface (src/planner/include/planner/moma_traj_opt.h:646-674) is one C++ object per
+candidate thread: `optimizeTraj(init_path, boundary_vel, boundary_acc) -> bool`, then `getTraj()` and the
+public `traj_cost`.  `MomaTrajOptBatch` keeps those names and argument meanings but takes a *batch* of
+candidates (one 64-lane wavefront each on the GPU).
+
+This module only binds `topay_amd/lib/libtopay_hip.so` (built by hipcc for gfx950).  There is no CPU
+path: if the library is missing, or no HIP device is usable, it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libtopay_hip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+
+class LbfgsParams(C.Structure):
+    _fields_ = [("mem_size", C.c_int), ("past", C.c_int), ("max_iterations", C.c_int), ("max_linesearch", C.c_int),
+                ("g_epsilon", C.c_double), ("delta", C.c_double), ("min_step", C.c_double), ("max_step", C.c_double),
+                ("f_dec_coeff", C.c_double), ("s_curv_coeff", C.c_double), ("cautious_factor", C.c_double),
+                ("machine_prec", C.c_double)]
+
+
+class Params(C.Structure):
+    """topay_params_t — mirrors MomaTrajOptParam (moma_traj_opt.h:441-564) + MomaParam constants."""
+    _fields_ = [
+        ("int_K", C.c_int), ("min_piece_num", C.c_int), ("relu_mu", C.c_double), ("sample_interval", C.c_double),
+        ("energy_weights", C.c_double * 9),
+        ("s1_time_weight", C.c_double), ("s1_moment_weight", C.c_double), ("s1_acc_weight", C.c_double),
+        ("s1_domega_weight", C.c_double), ("s1_path_pos_weight", C.c_double),
+        ("s1_normal_past", C.c_int), ("s1_shot_path_past", C.c_int), ("s1_shot_path_horizon", C.c_double),
+        ("s1_lbfgs", LbfgsParams),
+        ("s2_time_weight", C.c_double), ("s2_moment_weight", C.c_double), ("s2_acc_weight", C.c_double),
+        ("s2_domega_weight", C.c_double), ("s2_collision_weight", C.c_double), ("s2_mani_colli_weight", C.c_double),
+        ("s2_self_colli_weight", C.c_double), ("s2_mani_pos_weight", C.c_double), ("s2_mani_vel_weight", C.c_double),
+        ("s2_mani_acc_weight", C.c_double), ("s2_mean_time_weight", C.c_double),
+        ("s2_lbfgs", LbfgsParams),
+        ("alm_init_lambda", C.c_double * 2), ("alm_init_rho", C.c_double * 2), ("alm_rho_max", C.c_double * 2),
+        ("alm_gamma", C.c_double * 2), ("alm_tolerance", C.c_double), ("alm_max_outer", C.c_int),
+        ("chassis_height", C.c_double), ("chassis_colli_radius", C.c_double),
+        ("max_v", C.c_double), ("max_a", C.c_double), ("max_w", C.c_double), ("max_dw", C.c_double),
+        ("colli_length", C.c_double * 8), ("colli_points", C.c_double * 16), ("colli_point_radius", C.c_double * 16),
+        ("joint_pos_limit_max", C.c_double * 7), ("joint_vel_limit", C.c_double * 7), ("joint_acc_limit", C.c_double * 7),
+        ("relative_R", C.c_double * 9), ("relative_t", C.c_double * 3),
+    ]
+
+
+class MapDesc(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("resolution", C.c_double), ("dims", C.c_int * 3),
+                ("min_boundary", C.c_double * 3), ("max_boundary", C.c_double * 3)]
+
+
+class TopayError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load(path=None):
+    """Load the C-ABI library.  Default: the hipcc-built product library; raises if it is missing."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise TopayError(
+            f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "topay_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    L.topay_last_error.restype = C.c_char_p
+    L.topay_default_params.argtypes = [C.POINTER(Params)]
+    L.topay_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+    L.topay_destroy.argtypes = [C.c_void_p]
+    L.topay_set_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), c_dp, c_dp]
+    L.topay_set_init_traj.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
+    L.topay_reset.argtypes = [C.c_void_p]
+    L.topay_optimize.argtypes = [C.c_void_p]
+    L.topay_get_batch.argtypes = [C.c_void_p, c_ip, c_dp, c_ip]
+    L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
+    L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
+    L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
+    L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
+    L.topay_get_nmax.argtypes = [C.c_void_p, c_ip, c_ip]
+    L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
+    L.topay_last_kernel_ms.argtypes = [C.c_void_p, c_dp, c_ip]
+    L.topay_test_math.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
+    L.topay_set_trace.argtypes = [C.c_void_p, C.c_int]
+    L.topay_get_trace.argtypes = [C.c_void_p, C.c_int, c_dp]
+    _libs[path] = L
+    return L
+
+
+def default_params(lib=None):
+    L = lib or load()
+    p = Params()
+    _chk(L, L.topay_default_params(C.byref(p)))
+    return p
+
+
+def _chk(L, status):
+    if status != 0:
+        raise TopayError(f"topay status {status}: {L.topay_last_error().decode()}")
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None
+
+
+STAT_KEYS = ["stage1_ret", "stage1_iters", "stage1_evals", "stage2_last_ret", "stage2_iters", "stage2_evals",
+             "alm_outer", "sum_bound"]
+
+
+class MomaTrajOptBatch:
+    """Batched stand-in for `MomaTrajOpt` (reference: moma_traj_opt.h:613-674)."""
+
+    def __init__(self, params=None, device=0, lib_path=None):
+        self.L = load(lib_path)
+        self.opt_param = params if params is not None else default_params(self.L)
+        h = C.c_void_p()
+        _chk(self.L, self.L.topay_create(C.byref(self.opt_param), device, C.byref(h)))
+        self.h = h
+        self.batch = 0
+        self.traj_cost = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.topay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- MomaTrajOpt(GridMap::Ptr): the shared read-only map
+    def set_map(self, origin, resolution, dims, min_boundary, max_boundary, esdf2d, esdf3d, map_id=0):
+        d = MapDesc()
+        for i in range(3):
+            d.origin[i] = origin[i]
+            d.dims[i] = int(dims[i])
+            d.min_boundary[i] = min_boundary[i]
+            d.max_boundary[i] = max_boundary[i]
+        d.resolution = resolution
+        e2 = np.ascontiguousarray(esdf2d, dtype=np.float64)
+        e3 = np.ascontiguousarray(esdf3d, dtype=np.float64)
+        _chk(self.L, self.L.topay_set_map(self.h, map_id, C.byref(d), _dp(e2), _dp(e3)))
+
+    # -- optimizeTraj lines 146-357
+    def set_init_traj(self, path_len, init_paths, boundary_vel=None, boundary_acc=None, map_ids=None):
+        pl = np.ascontiguousarray(path_len, dtype=np.int32)
+        ip = np.ascontiguousarray(init_paths, dtype=np.float64)
+        bv = None if boundary_vel is None else np.ascontiguousarray(boundary_vel, dtype=np.float64)
+        ba = None if boundary_acc is None else np.ascontiguousarray(boundary_acc, dtype=np.float64)
+        mi = None if map_ids is None else np.ascontiguousarray(map_ids, dtype=np.int32)
+        self.batch = len(pl)
+        _chk(self.L, self.L.topay_set_init_traj(self.h, self.batch, _ip(pl), _dp(ip), _dp(bv), _dp(ba), _ip(mi)))
+
+    def reset(self):
+        _chk(self.L, self.L.topay_reset(self.h))
+
+    # -- optimizeTraj lines 359-497; returns the per-candidate bool of the reference
+    def optimize(self):
+        _chk(self.L, self.L.topay_optimize(self.h))
+        succ = np.zeros(self.batch, dtype=np.int32)
+        cost = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_get_batch(self.h, _ip(succ), _dp(cost), None))
+        self.traj_cost = cost
+        return succ.astype(bool)
+
+    def optimizeTraj(self, path_len, init_paths, boundary_vel=None, boundary_acc=None, map_ids=None):
+        self.set_init_traj(path_len, init_paths, boundary_vel, boundary_acc, map_ids)
+        return self.optimize()
+
+    def n_pieces(self):
+        n = np.zeros(self.batch, dtype=np.int32)
+        _chk(self.L, self.L.topay_get_batch(self.h, None, None, _ip(n)))
+        return n
+
+    # -- getTraj()
+    def getTraj(self, i):
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_get_result(self.h, i, None, None, C.byref(n), None, None, None))
+        N = n.value
+        dur = np.zeros(N)
+        coef = np.zeros(N * 54)
+        knots = np.zeros((N + 1) * 2)
+        succ = C.c_int(0)
+        cost = C.c_double(0)
+        _chk(self.L, self.L.topay_get_result(self.h, i, C.byref(succ), C.byref(cost), None, _dp(dur), _dp(coef), _dp(knots)))
+        return dict(success=bool(succ.value), cost=cost.value, durations=dur, coeffs=coef.reshape(N, 9, 6),
+                    knots_xy=knots.reshape(N + 1, 2))
+
+    def stats(self):
+        s = np.zeros(self.batch * 8, dtype=np.int32)
+        _chk(self.L, self.L.topay_get_stats(self.h, _ip(s)))
+        return s.reshape(self.batch, 8)
+
+    def get_x(self, i):
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_get_x(self.h, i, C.byref(n), None))
+        x = np.zeros(n.value)
+        _chk(self.L, self.L.topay_get_x(self.h, i, C.byref(n), _dp(x)))
+        return x
+
+    # -- firstStageCostCallback / secondStageCostCallback (test hook)
+    def eval(self, stage, i, x, alm_lambda=None, alm_rho=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros_like(x)
+        f = C.c_double(0)
+        e = np.zeros(2)
+        lam = None if alm_lambda is None else np.ascontiguousarray(alm_lambda, dtype=np.float64)
+        rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
+        _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
+        return f.value, g, e
+
+    def eval_batch(self, stage, repeats=1):
+        f = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_eval_batch(self.h, stage, repeats, _dp(f)))
+        return f
+
+    def set_trace(self, cap):
+        self._trace_cap = cap
+        _chk(self.L, self.L.topay_set_trace(self.h, cap))
+
+    def get_trace(self, i):
+        out = np.zeros(self._trace_cap)
+        _chk(self.L, self.L.topay_get_trace(self.h, i, _dp(out)))
+        return out
+
+    def test_math(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros(4 * len(a))
+        _chk(self.L, self.L.topay_test_math(self.h, len(a), _dp(a), _dp(b), _dp(out)))
+        return out.reshape(-1, 4)
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

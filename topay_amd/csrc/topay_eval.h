@@ -1,0 +1,1155 @@
+// One-wavefront-per-trajectory cost + analytic gradient of TopAY's (s,theta) NLP.
+//
+// Follows (all under /root/reference/src):
+//   planner/src/moma_traj_opt.cpp:817-955   first/secondStageCostCallback
+//   planner/src/moma_traj_opt.cpp:957-1198  calFirstStagePenalGrad
+//   planner/src/moma_traj_opt.cpp:1200-1829 calSecondStagePenalGrad
+//   planner/include/utils/minco.hpp:824-1069, banded_system.hpp:66-145
+//   simulator/fake_moma/include/fake_moma/moma_param.h:203-337, map/include/map/grid_map.h:364-509
+//
+// Work decomposition inside the wave (64 lanes, one workgroup = one wave):
+//   * "row lanes":    lane <-> row of the 6N x 6N MINCO system (2 rows per lane when 6N > 64).
+//                     They own the gradient w.r.t. the coefficient rows (gdC) in registers.
+//   * "sample lanes": lane <-> even ("full") Simpson sample e = 13*piece + m, 64 per pass.
+//                     Each also handles the odd sample that follows it.
+//   * banded LU / substitutions: the 6x7 (resp. 6x9) update block of one pivot across lanes, in LDS.
+// XY positions are a wave prefix scan of Simpson panel integrals; the XY-gradient "chain"
+// (moma_traj_opt.cpp:1313-1314,1667-1668,1812-1822) is the matching suffix scan, done in a second
+// sweep.  Per-sample gradient rows travel sample-lane -> row-lane through a small LDS pass buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "topay_math.h"
+#include "topay_types.h"
+
+#ifndef TOPAY_CPU_EMU
+#define HIP_DYN_SHARED_DECL extern __shared__ double topay_lds[];
+#endif
+
+namespace topay {
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers (collectives: call only from wave-uniform control flow)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+// inclusive prefix sum over lanes
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double o = __shfl_up(v, off);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+// inclusive suffix sum over lanes
+__device__ __forceinline__ double wave_incl_rscan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double o = __shfl_down(v, off);
+    if (lane + off < 64) v += o;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar pieces — moma_traj_opt.h:745-830
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double expC2(double tau) {
+  return tau > 0.0 ? ((0.5 * tau + 1.0) * tau + 1.0) : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
+}
+__device__ __forceinline__ double logC2(double T) {
+  return T > 1.0 ? (sqrt(2.0 * T - 1.0) - 1.0) : (1.0 - sqrt(2.0 / T - 1.0));
+}
+__device__ __forceinline__ double dTdTau(double tau) {
+  if (tau > 0) return tau + 1.0;
+  double den = (0.5 * tau - 1.0) * tau + 1.0;
+  return (1.0 - tau) / (den * den);
+}
+__device__ __forceinline__ double sigmoidC2(double vq, double max_q) {
+  double e = expC2(vq);
+  return 2.0 * max_q * e / (1.0 + e) - max_q;
+}
+__device__ __forceinline__ double invSigmoidC2(double q, double max_q) {
+  double b = 0.5 * (max_q + q) / max_q;
+  return logC2(b / (1 - b));
+}
+__device__ __forceinline__ double dQdVq(double vq, double max_q) {
+  double e1 = expC2(vq) + 1.0;
+  return 2.0 * max_q * dTdTau(vq) / (e1 * e1);
+}
+// smoothL1Penalty, only meaningful for x > 0 — moma_traj_opt.h:810-830
+__device__ __forceinline__ void smoothL1(double x, double mu, double& f, double& df) {
+  const double half = 0.5 * mu;
+  const double f3c = 1.0 / (mu * mu);
+  const double f4c = -0.5 * f3c / mu;
+  const double d2c = 3.0 * f3c;
+  const double d3c = 4.0 * f4c;
+  if (x < mu) {
+    f = (f4c * x + f3c) * x * x * x;
+    df = (d3c * x + d2c) * x * x;
+  } else {
+    f = x - half;
+    df = 1.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ESDF interpolation — grid_map.h:364-441 (2-D), 443-509 (3-D); out of map => d = 0, grad = 0
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void esdf2d_query(const DevMap& M, double px, double py, double& dist, double& gx, double& gy) {
+  bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4);
+  dist = 0.0; gx = 0.0; gy = 0.0;
+  if (in) {
+    const double r = M.res, ri = M.res_inv;
+    int ix = (int)floor((px - 0.5 * r - M.origin[0]) * ri);
+    int iy = (int)floor((py - 0.5 * r - M.origin[1]) * ri);
+    double dx = (px - ((ix + 0.5) * r + M.origin[0])) * ri;
+    double dy = (py - ((iy + 0.5) * r + M.origin[1])) * ri;
+    const int ny = M.dims[1];
+    int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
+    int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
+    const double* e = M.esdf2d;
+    double v00 = e[(size_t)x0 * ny + y0], v01 = e[(size_t)x0 * ny + y1];
+    double v10 = e[(size_t)x1 * ny + y0], v11 = e[(size_t)x1 * ny + y1];
+    double v0 = v00 * (1 - dx) + v10 * dx;
+    double v1 = v01 * (1 - dx) + v11 * dx;
+    dist = v0 * (1 - dy) + v1 * dy;
+    gy = (v1 - v0) * ri;
+    double g0 = (1 - dy) * (v10 - v00);
+    g0 += dy * (v11 - v01);
+    gx = g0 * ri;
+  }
+}
+
+__device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double py, double pz, double& dist, double& gx,
+                                             double& gy, double& gz) {
+  bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || pz < M.min_b[2] + 1e-4 ||
+              px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4 || pz > M.max_b[2] - 1e-4);
+  dist = 0.0; gx = 0.0; gy = 0.0; gz = 0.0;
+  if (in) {
+    const double r = M.res, ri = M.res_inv;
+    int ix = (int)floor((px - 0.5 * r - M.origin[0]) * ri);
+    int iy = (int)floor((py - 0.5 * r - M.origin[1]) * ri);
+    int iz = (int)floor((pz - 0.5 * r - M.origin[2]) * ri);
+    double dx = (px - ((ix + 0.5) * r + M.origin[0])) * ri;
+    double dy = (py - ((iy + 0.5) * r + M.origin[1])) * ri;
+    double dz = (pz - ((iz + 0.5) * r + M.origin[2])) * ri;
+    const int ny = M.dims[1], nz = M.dims[2];
+    int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
+    int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
+    int z0 = clampi(iz, nz - 1), z1 = clampi(iz + 1, nz - 1);
+    const double* e = M.esdf3d;
+    size_t b00 = ((size_t)x0 * ny + y0) * nz, b01 = ((size_t)x0 * ny + y1) * nz;
+    size_t b10 = ((size_t)x1 * ny + y0) * nz, b11 = ((size_t)x1 * ny + y1) * nz;
+    double v000 = e[b00 + z0], v001 = e[b00 + z1], v010 = e[b01 + z0], v011 = e[b01 + z1];
+    double v100 = e[b10 + z0], v101 = e[b10 + z1], v110 = e[b11 + z0], v111 = e[b11 + z1];
+    double v00 = v000 * (1 - dx) + v100 * dx;
+    double v01 = v001 * (1 - dx) + v101 * dx;
+    double v10 = v010 * (1 - dx) + v110 * dx;
+    double v11 = v011 * (1 - dx) + v111 * dx;
+    double v0 = v00 * (1 - dy) + v10 * dy;
+    double v1 = v01 * (1 - dy) + v11 * dy;
+    dist = v0 * (1.0 - dz) + v1 * dz;
+    gz = (v1 - v0) * ri;
+    gy = ((v10 - v00) * (1.0 - dz) + (v11 - v01) * dz) * ri;
+    double g0 = (1.0 - dz) * (1 - dy) * (v100 - v000);
+    g0 += (1.0 - dz) * dy * (v110 - v010);
+    g0 += dz * (1 - dy) * (v101 - v001);
+    g0 += dz * dy * (v111 - v011);
+    gx = g0 * ri;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level evaluation context: LDS carve-up + per-trajectory global pointers
+// ---------------------------------------------------------------------------------------------
+struct EvalCtx {
+  int lane, N, rows, n;
+  // LDS
+  double* cL;    // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
+  double* Tp;    // [5][N]     T, T^2..T^5
+  double* hp;    // [54]       head PVA (27) | tail PVA (27), 9x3 col-major
+  double* gdT;   // [N]        penalty dJ/dT accumulator
+  double* pcs;   // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
+  double* X;     // union region: band+rdiag+adjoint (23*rows) | sample buffers (26N + 512)
+  // global
+  const double* x;
+  double* g;
+  double* lu;         // [14*rows] stash
+  const double* init_xy;
+  double sx, sy, ex, ey;           // start xy, goal xy
+  double lam0, lam1, rho0, rho1;   // ALM state
+  double fxe0, fxe1;               // final_xy_error of this evaluation (stage 2)
+};
+
+__host__ __device__ __forceinline__ int lds_doubles(int Nmax) {
+  const int rows = 6 * Nmax;
+  int xr = 23 * rows;
+  int sr = 26 * Nmax + 512;
+  return 9 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + (xr > sr ? xr : sr);
+}
+__device__ __forceinline__ void carve(EvalCtx& C, double* base, int Nmax) {
+  const int rows = 6 * Nmax;
+  C.cL = base;
+  C.Tp = C.cL + 9 * rows;
+  C.hp = C.Tp + 5 * Nmax;
+  C.gdT = C.hp + 54;
+  C.pcs = C.gdT + Nmax;
+  C.X = C.pcs + 4 * (Nmax + 1);
+}
+
+#define BAND(i, j) band[((i) - (j) + 6) * rows + (j)]
+
+// MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
+// factors (+ reciprocal diagonal) stashed in C.lu.
+__device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
+  const int lane = C.lane, N = C.N, rows = C.rows;
+  double* band = C.X;
+  double* rdiag = C.X + 13 * rows;
+  double* cL = C.cL;
+  const double* Tau = C.x;
+  const double* Theta = C.x + N;
+  const double* Arc = C.x + 2 * N - 1;
+  const double* Vq = C.x + 3 * N - 1;
+
+  for (int t = lane; t < 13 * rows; t += 64) band[t] = 0.0;
+  for (int t = lane; t < 9 * rows; t += 64) cL[t] = 0.0;
+  if (lane < N) {
+    double T1 = expC2(Tau[lane]);  // calTfromTau, moma_traj_opt.h:778-786
+    double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
+    C.Tp[0 * N + lane] = T1; C.Tp[1 * N + lane] = T2; C.Tp[2 * N + lane] = T3;
+    C.Tp[3 * N + lane] = T4; C.Tp[4 * N + lane] = T5;
+    C.gdT[lane] = 0.0;
+  }
+  __syncthreads();
+  // band fill — minco.hpp:838-896
+  if (lane == 0) {
+    BAND(0, 0) = 1.0; BAND(1, 1) = 1.0; BAND(2, 2) = 2.0;
+  }
+  if (lane < N - 1) {
+    const int i = lane;
+    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    const int r = 6 * i;
+    BAND(r + 3, r + 3) = 6.0;  BAND(r + 3, r + 4) = 24.0 * T1; BAND(r + 3, r + 5) = 60.0 * T2; BAND(r + 3, r + 9) = -6.0;
+    BAND(r + 4, r + 4) = 24.0; BAND(r + 4, r + 5) = 120.0 * T1; BAND(r + 4, r + 10) = -24.0;
+    BAND(r + 5, r) = 1.0; BAND(r + 5, r + 1) = T1; BAND(r + 5, r + 2) = T2; BAND(r + 5, r + 3) = T3;
+    BAND(r + 5, r + 4) = T4; BAND(r + 5, r + 5) = T5;
+    BAND(r + 6, r) = 1.0; BAND(r + 6, r + 1) = T1; BAND(r + 6, r + 2) = T2; BAND(r + 6, r + 3) = T3;
+    BAND(r + 6, r + 4) = T4; BAND(r + 6, r + 5) = T5; BAND(r + 6, r + 6) = -1.0;
+    BAND(r + 7, r + 1) = 1.0; BAND(r + 7, r + 2) = 2 * T1; BAND(r + 7, r + 3) = 3 * T2; BAND(r + 7, r + 4) = 4 * T3;
+    BAND(r + 7, r + 5) = 5 * T4; BAND(r + 7, r + 7) = -1.0;
+    BAND(r + 8, r + 2) = 2.0; BAND(r + 8, r + 3) = 6 * T1; BAND(r + 8, r + 4) = 12 * T2; BAND(r + 8, r + 5) = 20 * T3;
+    BAND(r + 8, r + 8) = -2.0;
+  }
+  if (lane == 63) {
+    const int i = N - 1, R0 = 6 * N;
+    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    BAND(R0 - 3, R0 - 6) = 1.0; BAND(R0 - 3, R0 - 5) = T1; BAND(R0 - 3, R0 - 4) = T2; BAND(R0 - 3, R0 - 3) = T3;
+    BAND(R0 - 3, R0 - 2) = T4; BAND(R0 - 3, R0 - 1) = T5;
+    BAND(R0 - 2, R0 - 5) = 1.0; BAND(R0 - 2, R0 - 4) = 2 * T1; BAND(R0 - 2, R0 - 3) = 3 * T2; BAND(R0 - 2, R0 - 2) = 4 * T3;
+    BAND(R0 - 2, R0 - 1) = 5 * T4;
+    BAND(R0 - 1, R0 - 4) = 2; BAND(R0 - 1, R0 - 3) = 6 * T1; BAND(R0 - 1, R0 - 2) = 12 * T2; BAND(R0 - 1, R0 - 1) = 20 * T3;
+  }
+  // right-hand side — minco.hpp:841-843, 879, 898-900; inner points from x (moma_traj_opt.cpp:904-913)
+  if (lane < 9) {
+    const int d = lane;
+    cL[d * rows + 0] = C.hp[0 * 9 + d];
+    cL[d * rows + 1] = C.hp[1 * 9 + d];
+    cL[d * rows + 2] = C.hp[2 * 9 + d];
+    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : C.hp[27 + 0 * 9 + d];  // minco_end_state(1,0) = Arc[N-1]
+    cL[d * rows + rows - 2] = C.hp[27 + 1 * 9 + d];
+    cL[d * rows + rows - 1] = C.hp[27 + 2 * 9 + d];
+  }
+  for (int t = lane; t < 9 * (N - 1); t += 64) {
+    const int i = t / 9, d = t - 9 * i;
+    double v;
+    if (d == 0) v = Theta[i];
+    else if (d == 1) v = Arc[i];
+    else v = sigmoidC2(Vq[i * 7 + d - 2], P.joint_pos_limit_max[d - 2]);
+    cL[d * rows + 6 * i + 5] = v;
+  }
+  __syncthreads();
+
+  // LU without pivoting — banded_system.hpp:66-91.  Lane (t,u): row i = k+t (t=1..6), column j = k+u
+  // (u=0 stores the multiplier, u=1..6 the rank-1 update).  The zero-skip tests of the reference
+  // are arithmetic no-ops (0/x = 0, a - 0*c = a).
+  {
+    const int t = lane / 7 + 1, u = lane - (lane / 7) * 7;
+    for (int k = 0; k <= rows - 2; k++) {
+      const int i = k + t, j = k + u;
+      const bool act = (lane < 42) && (i < rows) && (j < rows);
+      double nv = 0.0;
+      if (act) {
+        const double akk = BAND(k, k), aik = BAND(i, k);
+        const double m = aik / akk;
+        nv = (u == 0) ? m : (BAND(i, j) - m * BAND(k, j));
+      }
+      __syncthreads();
+      if (act) BAND(i, j) = nv;
+      __syncthreads();
+    }
+  }
+  for (int t = lane; t < rows; t += 64) rdiag[t] = 1.0 / BAND(t, t);
+  __syncthreads();
+  // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118
+  {
+    const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
+    for (int j = 0; j < rows; j++) {
+      const int i = j + t;
+      if (lane < 54 && i < rows) cL[d * rows + i] -= BAND(i, j) * cL[d * rows + j];
+      __syncthreads();
+    }
+    // rows stay unscaled during the sweep; b(j)/A(j,j) is formed on the fly and applied at the end
+    for (int j = rows - 1; j >= 0; j--) {
+      const int i = j - t;
+      if (lane < 54 && i >= 0) cL[d * rows + i] -= BAND(i, j) * (cL[d * rows + j] * rdiag[j]);
+      __syncthreads();
+    }
+  }
+  for (int t = lane; t < 9 * rows; t += 64) {
+    const int row = t % rows;
+    cL[t] *= rdiag[row];
+  }
+  // stash LU + reciprocal diagonal for the adjoint solve
+  for (int t = lane; t < 14 * rows; t += 64) C.lu[t] = C.X[t];
+  __syncthreads();
+}
+
+// polynomial basis of local time s: b0 = s^k, b1, b2, b3 derivatives — moma_traj_opt.cpp:1263-1270
+struct Basis {
+  double b0[6], b1[6], b2[6], b3[6];
+};
+__device__ __forceinline__ void make_basis(double s1, Basis& B) {
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
+  B.b0[0] = 1.0; B.b0[1] = s1; B.b0[2] = s2; B.b0[3] = s3; B.b0[4] = s4; B.b0[5] = s5;
+  B.b1[0] = 0.0; B.b1[1] = 1.0; B.b1[2] = 2.0 * s1; B.b1[3] = 3.0 * s2; B.b1[4] = 4.0 * s3; B.b1[5] = 5.0 * s4;
+  B.b2[0] = 0.0; B.b2[1] = 0.0; B.b2[2] = 2.0; B.b2[3] = 6.0 * s1; B.b2[4] = 12.0 * s2; B.b2[5] = 20.0 * s3;
+  B.b3[0] = 0.0; B.b3[1] = 0.0; B.b3[2] = 0.0; B.b3[3] = 6.0; B.b3[4] = 24.0 * s1; B.b3[5] = 60.0 * s2;
+}
+// value and derivatives of dimension d of piece i at the basis point (reads 6 coefficients from LDS)
+__device__ __forceinline__ void poly4(const double* cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
+                                      double& p2, double& p3) {
+  const double* c = cL + d * rows + 6 * i;
+  const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+  p0 = c0 * B.b0[0] + c1 * B.b0[1] + c2 * B.b0[2] + c3 * B.b0[3] + c4 * B.b0[4] + c5 * B.b0[5];
+  p1 = c1 * B.b1[1] + c2 * B.b1[2] + c3 * B.b1[3] + c4 * B.b1[4] + c5 * B.b1[5];
+  p2 = c2 * B.b2[2] + c3 * B.b2[3] + c4 * B.b2[4] + c5 * B.b2[5];
+  p3 = c3 * B.b3[3] + c4 * B.b3[4] + c5 * B.b3[5];
+}
+__device__ __forceinline__ void poly3(const double* cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
+                                      double& p2) {
+  const double* c = cL + d * rows + 6 * i;
+  const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+  p0 = c0 * B.b0[0] + c1 * B.b0[1] + c2 * B.b0[2] + c3 * B.b0[3] + c4 * B.b0[4] + c5 * B.b0[5];
+  p1 = c1 * B.b1[1] + c2 * B.b1[2] + c3 * B.b1[3] + c4 * B.b1[4] + c5 * B.b1[5];
+  p2 = c2 * B.b2[2] + c3 * B.b2[3] + c4 * B.b2[4] + c5 * B.b2[5];
+}
+
+// integrand of the Simpson XY integral at local time s of piece i: sdot*(cos th, sin th)
+__device__ __forceinline__ void xy_integrand(const double* cL, int rows, int i, double s1, double& fx, double& fy) {
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
+  const double* ct = cL + 0 * rows + 6 * i;
+  const double* cs = cL + 1 * rows + 6 * i;
+  const double th = ct[0] + ct[1] * s1 + ct[2] * s2 + ct[3] * s3 + ct[4] * s4 + ct[5] * s5;
+  const double sd = cs[1] + cs[2] * (2.0 * s1) + cs[3] * (3.0 * s2) + cs[4] * (4.0 * s3) + cs[5] * (5.0 * s4);
+  double sn, cn;
+  det_sincos(th, &sn, &cn);
+  fx = sd * cn;
+  fy = sd * sn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage-2 manipulator block of one even sample: FK (moma_param.h:203-247), 12 ESDF lookups
+// (moma_traj_opt.cpp:1477-1520), self collision (1521-1612), Jacobian-transpose (moma_param.h:249-337),
+// joint position limits (1616-1666).
+//
+// World sphere centre  P_k = p0 + A * rho_k,  A = Rz(theta) * relative_R,  p0 = (x, y, h) + Rz(theta) * relative_t,
+// where rho_k comes from the joint chain run in the arm-local frame (pure rotations).  relative_R is the
+// reference's 0.7071068 literal matrix, i.e. not exactly orthonormal, so the joint torques are formed in the local
+// frame from g' = A^T g:  tau_i = u_i . sum (rho - o_{i+1}) x g'  — the exact derivative of the reference's matrix
+// products for any A, unlike the world-frame axis x r form.  Yaw and x, y are taken in the world frame (Rz exact).
+// pos = (x, y, theta, q1..q7).  Returns cost and the "/K" gdT part; moma_grad[10] = d/d(x, y, theta, q).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void joint_rotate(double* R, int i, double c_, double s_) {
+  if (i % 2 == 0) {  // R <- R * Rz(q): mixes columns 0,1
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double r0 = R[a * 3 + 0], r1 = R[a * 3 + 1];
+      R[a * 3 + 0] = r0 * c_ + r1 * s_;
+      R[a * 3 + 1] = -r0 * s_ + r1 * c_;
+    }
+  } else {  // R <- R * Ry(q): mixes columns 0,2
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double r0 = R[a * 3 + 0], r2 = R[a * 3 + 2];
+      R[a * 3 + 0] = r0 * c_ - r2 * s_;
+      R[a * 3 + 2] = r0 * s_ + r2 * c_;
+    }
+  }
+}
+
+__device__ __forceinline__ void manipulator_block(const DevParams& P, const DevMap& M, const double* pos, double omg,
+                                                  double step, double sth, double cth, double* moma_grad, double& cost,
+                                                  double& gdTk) {
+  const double mu = P.relu_mu;
+  const double w = omg * step;
+  double sq[7], cq[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) det_sincos(pos[3 + i], &sq[i], &cq[i]);
+  double A[9];
+  {
+    const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++)
+        A[a * 3 + b] = Rz[a * 3 + 0] * P.relR[0 * 3 + b] + Rz[a * 3 + 1] * P.relR[1 * 3 + b] + Rz[a * 3 + 2] * P.relR[2 * 3 + b];
+  }
+  const double p0x = pos[0] + (cth * P.relT[0] - sth * P.relT[1]);
+  const double p0y = pos[1] + (sth * P.relT[0] + cth * P.relT[1]);
+  const double p0z = P.chassis_height + P.relT[2];
+  double Lx[TOPAY_NSPH], Ly[TOPAY_NSPH], Lz[TOPAY_NSPH];  // arm-local sphere centres rho_k
+  // spheres per link: link0:{0,1} 1:{2} 2:{3,4} 3:{5} 4:{6,7} 5:{8} 6:{9,10} 7:{11}
+  {
+    double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int cnt = (i % 2 == 0) ? 2 : 1;
+#pragma unroll
+      for (int c = 0; c < cnt; c++) {
+        Lx[sidx] = q0 + R[2] * P.sph_off[sidx];
+        Ly[sidx] = q1 + R[5] * P.sph_off[sidx];
+        Lz[sidx] = q2 + R[8] * P.sph_off[sidx];
+        sidx++;
+      }
+      q0 += R[2] * P.colli_length[i];
+      q1 += R[5] * P.colli_length[i];
+      q2 += R[8] * P.colli_length[i];
+      if (i == 7) break;
+      joint_rotate(R, i, cq[i], sq[i]);
+    }
+  }
+  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    Px[k] = p0x + (A[0] * Lx[k] + A[1] * Ly[k] + A[2] * Lz[k]);
+    Py[k] = p0y + (A[3] * Lx[k] + A[4] * Ly[k] + A[5] * Lz[k]);
+    Pz[k] = p0z + (A[6] * Lx[k] + A[7] * Ly[k] + A[8] * Lz[k]);
+  }
+  double Gx[TOPAY_NSPH], Gy[TOPAY_NSPH], Gz[TOPAY_NSPH];
+  cost = 0.0;
+  gdTk = 0.0;
+  const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
+  // environment collision
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    double d, gx, gy, gz;
+    esdf3d_query(M, Px[k], Py[k], Pz[k], d, gx, gy, gz);
+    const double viola = P.sph_r[k] * 10.0 * 1.1 - d * 10.0;
+    Gx[k] = 0.0; Gy[k] = 0.0; Gz[k] = 0.0;
+    if (viola > 0) {
+      double pe, pd;
+      smoothL1(viola, mu, pe, pd);
+      const double sc = -w * wMC * pd;
+      Gx[k] = sc * gx * 10.0; Gy[k] = sc * gy * 10.0; Gz[k] = sc * gz * 10.0;
+      gdTk += omg * wMC * (pe / TOPAY_K);
+      cost += w * wMC * pe;
+    }
+  }
+  // chassis top — spheres with index > 2
+#pragma unroll
+  for (int k = 3; k < TOPAY_NSPH; k++) {
+    const double height = P.chassis_height + P.relT[2] + P.sph_r[k] - Pz[k];
+    if (height > 0) {
+      double pe, pd;
+      smoothL1(height, mu, pe, pd);
+      Gz[k] += -w * wSC * pd;
+      gdTk += omg * wSC * (pe / TOPAY_K);
+      cost += w * wSC * pe;
+    }
+  }
+  // sphere pairs: collision_matrix == -1 <=> non-adjacent spheres (moma_param.h:128-143: at the zero pose
+  // only self and neighbouring spheres overlap)
+#pragma unroll
+  for (int a = 0; a < TOPAY_NSPH; a++)
+#pragma unroll
+    for (int b = a + 2; b < TOPAY_NSPH; b++) {
+      const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
+      const double rr = P.sph_r[a] + P.sph_r[b];
+      const double dist = rr * rr - (dx * dx + dy * dy + dz * dz);
+      if (dist > 0) {
+        double pe, pd;
+        smoothL1(dist, mu, pe, pd);
+        const double sc = -w * wSC * pd * 2.0;
+        Gx[a] += sc * dx; Gy[a] += sc * dy; Gz[a] += sc * dz;
+        Gx[b] -= sc * dx; Gy[b] -= sc * dy; Gz[b] -= sc * dz;
+        gdTk += omg * wSC * (pe / TOPAY_K);
+        cost += w * wSC * pe;
+      }
+    }
+  // base: x, y and yaw (everything rotates about the vertical axis through (x, y))
+  {
+    double Fx = 0, Fy = 0, Mz = 0;
+#pragma unroll
+    for (int k = 0; k < TOPAY_NSPH; k++) {
+      Fx += Gx[k]; Fy += Gy[k];
+      Mz += (Px[k] - pos[0]) * Gy[k] - (Py[k] - pos[1]) * Gx[k];
+    }
+    moma_grad[0] = Fx;
+    moma_grad[1] = Fy;
+    moma_grad[2] = Mz;
+  }
+  // joints: g' = A^T g in the arm-local frame, then walk the chain again peeling off the links at or below
+  // each joint:  tau_i = u_i . (Mo_beyond - o_{i+1} x F_beyond)
+  double Fx = 0, Fy = 0, Fz = 0, Mx = 0, My = 0, Mz = 0;
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    const double gx = A[0] * Gx[k] + A[3] * Gy[k] + A[6] * Gz[k];
+    const double gy = A[1] * Gx[k] + A[4] * Gy[k] + A[7] * Gz[k];
+    const double gz = A[2] * Gx[k] + A[5] * Gy[k] + A[8] * Gz[k];
+    Gx[k] = gx; Gy[k] = gy; Gz[k] = gz;
+    Fx += gx; Fy += gy; Fz += gz;
+    Mx += Ly[k] * gz - Lz[k] * gy;
+    My += Lz[k] * gx - Lx[k] * gz;
+    Mz += Lx[k] * gy - Ly[k] * gx;
+  }
+  {
+    double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      const int cnt = (i % 2 == 0) ? 2 : 1;
+#pragma unroll
+      for (int c = 0; c < cnt; c++) {  // remove link i's spheres from the "beyond" sums
+        Fx -= Gx[sidx]; Fy -= Gy[sidx]; Fz -= Gz[sidx];
+        Mx -= Ly[sidx] * Gz[sidx] - Lz[sidx] * Gy[sidx];
+        My -= Lz[sidx] * Gx[sidx] - Lx[sidx] * Gz[sidx];
+        Mz -= Lx[sidx] * Gy[sidx] - Ly[sidx] * Gx[sidx];
+        sidx++;
+      }
+      o0 += R[2] * P.colli_length[i];
+      o1 += R[5] * P.colli_length[i];
+      o2 += R[8] * P.colli_length[i];
+      // joint i turns frame i about its local z (even i) or y (odd i) axis through o_{i+1}
+      const int ac = (i % 2 == 0) ? 2 : 1;
+      const double ax = R[0 * 3 + ac], ay = R[1 * 3 + ac], az = R[2 * 3 + ac];
+      const double tx = Mx - (o1 * Fz - o2 * Fy);
+      const double ty = My - (o2 * Fx - o0 * Fz);
+      const double tz = Mz - (o0 * Fy - o1 * Fx);
+      moma_grad[3 + i] = ax * tx + ay * ty + az * tz;
+      joint_rotate(R, i, cq[i], sq[i]);
+    }
+  }
+  // joint position limits — moma_traj_opt.cpp:1616-1666 (symmetric joint_pos_limit_max, reference quirk)
+  const double wJP = P.s2_mani_pos_weight;
+#pragma unroll
+  for (int ji = 0; ji < 7; ji++) {
+    double v = pos[ji + 3] - P.joint_pos_limit_max[ji];
+    if (v > 0) {
+      double pe, pd;
+      smoothL1(v, mu, pe, pd);
+      moma_grad[ji + 3] += w * wJP * pd;
+      gdTk += omg * wJP * (pe / TOPAY_K);
+      cost += w * wJP * pe;
+    }
+    v = -P.joint_pos_limit_max[ji] - pos[ji + 3];
+    if (v > 0) {
+      double pe, pd;
+      smoothL1(v, mu, pe, pd);
+      moma_grad[ji + 3] -= w * wJP * pd;
+      gdTk += omg * wJP * (pe / TOPAY_K);
+      cost += w * wJP * pe;
+    }
+  }
+}
+
+// kinodynamic penalties shared by both stages — moma_traj_opt.cpp:1059-1115 / 1334-1462.
+// th1,th2,th3 = theta', theta'', theta'''; s1..s3 likewise.  Adds to cost, gdT and the gradBeta entries
+// (gth1 = d/d theta', gth2 = d/d theta'', gs1, gs2).
+__device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM, double wA, double wD, double omg,
+                                                  double step, double real_alpha, double th1, double th2, double th3,
+                                                  double sd1, double sd2, double sd3, double& cost, double& gdT,
+                                                  double& gth1, double& gth2, double& gs1, double& gs2) {
+  const double mu = P.relu_mu;
+  const double max_v = P.max_v, max_w = P.max_w, max_a = P.max_a, max_dw = P.max_dw;
+  const double w = omg * step;
+#pragma unroll
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    const double v = sgn * max_v * th1 + max_w * sd1 - max_v * max_w;
+    if (v > 0) {
+      double pe, pd;
+      smoothL1(v, mu, pe, pd);
+      const double gt = real_alpha * (sgn * max_v * th2 + max_w * sd2);
+      gth1 += w * wM * pd * sgn * max_v;
+      gs1 += w * wM * pd * max_w;
+      gdT += omg * wM * (pd * gt * step + pe / TOPAY_K);
+      cost += w * wM * pe;
+    }
+  }
+#pragma unroll
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    const double v = sgn * max_v * th1 - max_w * sd1 - max_v * max_w;
+    if (v > 0) {
+      double pe, pd;
+      smoothL1(v, mu, pe, pd);
+      const double gt = real_alpha * (sgn * max_v * th2 - max_w * sd2);
+      gth1 += w * wM * pd * sgn * max_v;
+      gs1 -= w * wM * pd * max_w;
+      gdT += omg * wM * (pd * gt * step + pe / TOPAY_K);
+      cost += w * wM * pe;
+    }
+  }
+  const double vAcc = sd2 * sd2 - max_a * max_a;
+  const double vAlp = th2 * th2 - max_dw * max_dw;
+  if (vAcc > 0) {
+    double pe, pd;
+    smoothL1(vAcc, mu, pe, pd);
+    const double gt = 2.0 * real_alpha * sd2 * sd3;
+    gs2 += w * wA * pd * 2.0 * sd2;
+    gdT += omg * wA * (pd * gt * step + pe / TOPAY_K);
+    cost += w * wA * pe;
+  }
+  if (vAlp > 0) {
+    double pe, pd;
+    smoothL1(vAlp, mu, pe, pd);
+    const double gt = 2.0 * real_alpha * th2 * th3;
+    gth2 += w * wD * pd * 2.0 * th2;
+    gdT += omg * wD * (pd * gt * step + pe / TOPAY_K);
+    cost += w * wD * pe;
+  }
+}
+
+// k-th basis entries of order 0,1,2 at local time s (k = coefficient index of a row lane)
+__device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1, double& b2) {
+  // powers s^(k-2), s^(k-1), s^k with the convention s^negative -> unused (multiplied by 0)
+  double pm2 = 1.0, pm1 = 1.0, p = 1.0;
+#pragma unroll
+  for (int t = 1; t <= 5; t++) {
+    if (t <= k) p *= s;
+    if (t <= k - 1) pm1 *= s;
+    if (t <= k - 2) pm2 *= s;
+  }
+  b0 = p;
+  b1 = (k >= 1) ? (double)k * pm1 : 0.0;
+  b2 = (k >= 2) ? (double)(k * (k - 1)) * pm2 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The evaluation.  STAGE = 1: firstStageCostCallback; STAGE = 2: secondStageCostCallback.
+// RMAX = rows per lane (1: N <= 10, 2: N <= 21).  Returns f (wave-uniform); writes g[n].
+// ---------------------------------------------------------------------------------------------
+template <int STAGE, int RMAX>
+__device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P, const DevMap& M) {
+  const int lane = C.lane, N = C.N, rows = C.rows;
+  const double* cL = C.cL;
+  minco_generate(C, P);
+
+  // ---- jerk energy & dJ/dT per piece — minco.hpp:923-942, 978-994 (lanes <-> pieces)
+  double jerk_gdT = 0.0, jerk_e = 0.0;
+  if (lane < N) {
+    const int i = lane;
+    double w33 = 0, w43 = 0, w44 = 0, w53 = 0, w54 = 0, w55 = 0;
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+      const double c3 = cL[d * rows + 6 * i + 3], c4 = cL[d * rows + 6 * i + 4], c5 = cL[d * rows + 6 * i + 5];
+      const double e = P.energy_weights[d];
+      w33 += (c3 * e) * c3; w43 += (c4 * e) * c3; w44 += (c4 * e) * c4;
+      w53 += (c5 * e) * c3; w54 += (c5 * e) * c4; w55 += (c5 * e) * c5;
+    }
+    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    jerk_e = 36.0 * w33 * T1 + 144.0 * w43 * T2 + 192.0 * w44 * T3 + 240.0 * w53 * T3 + 720.0 * w54 * T4 + 720.0 * w55 * T5;
+    jerk_gdT = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
+  }
+  const double jerk_cost = wave_sum(jerk_e);
+
+  // ---- row-lane bookkeeping
+  int rrow[RMAX], rpiece[RMAX], rk[RMAX];
+  bool ract[RMAX];
+  double acc[RMAX][9];
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    rrow[r] = lane + 64 * r;
+    ract[r] = rrow[r] < rows;
+    rpiece[r] = rrow[r] / 6;
+    rk[r] = rrow[r] - 6 * rpiece[r];
+#pragma unroll
+    for (int d = 0; d < 9; d++) acc[r][d] = 0.0;
+  }
+
+  double* gxy = C.X;                 // [13N][2] positional gradient of each even sample
+  double* pbuf = C.X + 26 * N;       // [8][64] pass buffer
+  const int NE = TOPAY_EP * N;       // even samples
+  const int npass = (NE + 63) / 64;
+  double cost_pen = 0.0;             // per-lane partial penalty cost
+  double carryx = 0.0, carryy = 0.0; // XY prefix carried across passes (relative to start)
+
+  const double wM = STAGE == 1 ? P.s1_moment_weight : P.s2_moment_weight;
+  const double wA = STAGE == 1 ? P.s1_acc_weight : P.s2_acc_weight;
+  const double wD = STAGE == 1 ? P.s1_domega_weight : P.s2_domega_weight;
+
+  // =========================== sweep 1: forward over even samples ===========================
+  for (int pass = 0; pass < npass; pass++) {
+    const int e = pass * 64 + lane;
+    const bool act = e < NE;
+    const int i = act ? e / TOPAY_EP : N - 1;
+    const int m = act ? e - TOPAY_EP * i : 0;
+    const int j = 2 * m;
+    const double T1 = C.Tp[i];
+    const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
+    // Simpson panel m of piece i: samples j, j+1, j+2 — moma_traj_opt.cpp:1282-1291, 1731-1732
+    double f0x, f0y, Ix = 0.0, Iy = 0.0;
+    xy_integrand(cL, rows, i, j * half, f0x, f0y);
+    if (act && m < TOPAY_K) {
+      double f1x, f1y, f2x, f2y;
+      xy_integrand(cL, rows, i, (j + 1) * half, f1x, f1y);
+      xy_integrand(cL, rows, i, (j + 2) * half, f2x, f2y);
+      Ix = coeff * f0x + 4 * coeff * f1x + coeff * f2x;
+      Iy = coeff * f0y + 4 * coeff * f1y + coeff * f2y;
+    }
+    const double incx = wave_incl_scan(Ix, lane), incy = wave_incl_scan(Iy, lane);
+    const double posx = C.sx + (carryx + (incx - Ix));  // CurrentXY at this even sample
+    const double posy = C.sy + (carryy + (incy - Iy));
+    const double totx = __shfl(incx, 63), toty = __shfl(incy, 63);
+    carryx += totx;
+    carryy += toty;
+    if (act && m == TOPAY_K) {  // piece end: VecTrajFinalXY[i+1] — moma_traj_opt.cpp:1750
+      C.pcs[2 * N + 2 * (i + 1)] = posx;
+      C.pcs[2 * N + 2 * (i + 1) + 1] = posy;
+    }
+
+    double gB[12];
+#pragma unroll
+    for (int v = 0; v < 12; v++) gB[v] = 0.0;
+    double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
+    bool jva = false;
+    if (act) {
+      Basis B;
+      make_basis(j * half, B);
+      const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
+      const double real_alpha = 1.0 / TOPAY_K * ((double)j / 2.0);
+      double th0, th1, th2, th3, s0, sd1, sd2, sd3;
+      poly4(cL, rows, i, 0, B, th0, th1, th2, th3);
+      poly4(cL, rows, i, 1, B, s0, sd1, sd2, sd3);
+      double cst = 0.0;
+      kinodynamic_block(P, wM, wA, wD, omg, step, real_alpha, th1, th2, th3, sd1, sd2, sd3, cst, gdTs, gB[1], gB[2],
+                        gB[3], gB[4]);
+      if (STAGE == 2) {
+        double sth, cth;
+        det_sincos(th0, &sth, &cth);
+        // chassis collision — moma_traj_opt.cpp:1304-1332
+        double d2, g2x, g2y;
+        esdf2d_query(M, posx, posy, d2, g2x, g2y);
+        const double viola = P.chassis_colli_radius * 1.05 - d2;
+        if (viola > 0) {
+          double pe, pd;
+          smoothL1(viola, P.relu_mu, pe, pd);
+          const double sc = -omg * step * P.s2_collision_weight * pd;
+          gpx += sc * g2x;
+          gpy += sc * g2y;
+          gdTs += omg * P.s2_collision_weight * (pe / TOPAY_K);
+          cst += omg * step * P.s2_collision_weight * pe;
+        }
+        // manipulator
+        double pos[10], q1[7];
+        pos[0] = posx; pos[1] = posy; pos[2] = th0;
+        double qacc = 0.0;  // moma_grad.tail(7) . dq
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+          double a0, a1, a2, a3;
+          poly4(cL, rows, i, 2 + q, B, a0, a1, a2, a3);
+          pos[3 + q] = a0;
+          q1[q] = a1;
+          // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the
+          // rare gradBeta rows are produced in the follow-up round when any lane is active)
+          const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
+          const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+          if (vDq > 0) {
+            double pe, pd;
+            smoothL1(vDq, P.relu_mu, pe, pd);
+            gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe / TOPAY_K);
+            cst += omg * step * P.s2_mani_vel_weight * pe;
+            jva = true;
+          }
+          if (vD2q > 0) {
+            double pe, pd;
+            smoothL1(vD2q, P.relu_mu, pe, pd);
+            gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe / TOPAY_K);
+            cst += omg * step * P.s2_mani_acc_weight * pe;
+            jva = true;
+          }
+        }
+        double mg[10], mcost, mgdT;
+        manipulator_block(P, M, pos, omg, step, sth, cth, mg, mcost, mgdT);
+        cst += mcost;
+        gdTs += mgdT;
+        gpx += mg[0];
+        gpy += mg[1];
+        gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
+        gdTs += mg[2] * th1 * real_alpha;   // (1670)
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+          gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
+          qacc += mg[3 + q] * q1[q];
+        }
+        gdTs += qacc * real_alpha;          // (1672)
+      }
+      cost_pen += cst;
+    }
+    if (act) {
+      gxy[2 * e] = gpx;
+      gxy[2 * e + 1] = gpy;
+    }
+    // ---- hand the per-sample gradient rows to the row lanes.  Round A: theta/s rows + gdT
+#pragma unroll
+    for (int v = 0; v < 5; v++) pbuf[v * 64 + lane] = gB[v];
+    pbuf[5 * 64 + lane] = gdTs;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+      if (ract[r]) {
+        const int pi = rpiece[r];
+        const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+        const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+        double gt = 0.0;
+        for (int ee = e_lo; ee < e_hi; ee++) {
+          const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+          double b0, b1, b2;
+          basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
+          acc[r][0] += b0 * pbuf[0 * 64 + l] + b1 * pbuf[1 * 64 + l] + b2 * pbuf[2 * 64 + l];
+          acc[r][1] += b1 * pbuf[3 * 64 + l] + b2 * pbuf[4 * 64 + l];
+          gt += pbuf[5 * 64 + l];
+        }
+        if (rk[r] == 0) C.gdT[pi] += gt;
+      }
+    }
+    __syncthreads();
+    if (STAGE == 2) {
+      // Round B: joint rows of order 0
+#pragma unroll
+      for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = gB[5 + v];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) {
+        if (ract[r]) {
+          const int pi = rpiece[r];
+          const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+          const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+          for (int ee = e_lo; ee < e_hi; ee++) {
+            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+            double b0, b1, b2;
+            basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
+#pragma unroll
+            for (int q = 0; q < 7; q++) acc[r][2 + q] += b0 * pbuf[q * 64 + l];
+          }
+        }
+      }
+      __syncthreads();
+      // Round C (rare): joint velocity / acceleration gradBeta rows 1 and 2 — moma_traj_opt.cpp:1689, 1703
+      if (__any(jva)) {
+        double g1[7], g2[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) { g1[q] = 0.0; g2[q] = 0.0; }
+        if (act && jva) {
+          Basis B;
+          make_basis(j * half, B);
+          const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
+#pragma unroll
+          for (int q = 0; q < 7; q++) {
+            double a0, a1, a2;
+            poly3(cL, rows, i, 2 + q, B, a0, a1, a2);
+            const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
+            const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+            if (vDq > 0) {
+              double pe, pd;
+              smoothL1(vDq, P.relu_mu, pe, pd);
+              g1[q] = omg * step * P.s2_mani_vel_weight * pd * 2.0 * a1;
+            }
+            if (vD2q > 0) {
+              double pe, pd;
+              smoothL1(vD2q, P.relu_mu, pe, pd);
+              g2[q] = omg * step * P.s2_mani_acc_weight * pd * 2.0 * a2;
+            }
+          }
+        }
+#pragma unroll
+        for (int half_r = 0; half_r < 2; half_r++) {
+#pragma unroll
+          for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = half_r == 0 ? g1[v] : g2[v];
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < RMAX; r++) {
+            if (ract[r]) {
+              const int pi = rpiece[r];
+              const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+              const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+              for (int ee = e_lo; ee < e_hi; ee++) {
+                const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+                double b0, b1, b2;
+                basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
+                const double bb = half_r == 0 ? b1 : b2;
+#pragma unroll
+                for (int q = 0; q < 7; q++) acc[r][2 + q] += bb * pbuf[q * 64 + l];
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  // ---- per-piece terms between the sweeps
+  double cost_piece = 0.0;
+  double chain0x = 0.0, chain0y = 0.0;  // constant added to every chain entry (ALM term)
+  if (STAGE == 1) {
+    // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
+    __syncthreads();
+    if (lane < N) {
+      const double ex = C.pcs[2 * N + 2 * (lane + 1)] - C.init_xy[2 * lane];
+      const double ey = C.pcs[2 * N + 2 * (lane + 1) + 1] - C.init_xy[2 * lane + 1];
+      cost_piece = P.s1_path_pos_weight * (ex * ex + ey * ey);
+      C.pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
+      C.pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
+    }
+    __syncthreads();
+  } else {
+    // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
+    const double Tm = lane < N ? C.Tp[lane] : 0.0;
+    const double avg = wave_sum(Tm) / N;
+    double add_all = 0.0, add_own = 0.0;
+    if (lane < N) {
+      const double wMT = P.s2_mean_time_weight;
+      if (Tm < avg * 0.5) {
+        const double dd = Tm - avg * 0.5;
+        cost_piece += wMT * dd * dd;
+        add_all += wMT * 2.0 * dd * (-0.5 / N);
+        add_own += wMT * 2.0 * dd;
+      }
+      if (Tm > avg * 2.0) {
+        const double dd = Tm - avg * 2.0;
+        cost_piece += wMT * dd * dd;
+        add_all += wMT * 2.0 * dd * (-2.0 / N);
+        add_own += wMT * 2.0 * dd;
+      }
+    }
+    const double all = wave_sum(add_all);
+    if (lane < N) C.gdT[lane] += all + add_own;
+    // ALM end-point term — moma_traj_opt.cpp:1785-1810
+    C.fxe0 = (C.sx + carryx) - C.ex;
+    C.fxe1 = (C.sy + carryy) - C.ey;
+    const double ea = C.fxe0 + C.lam0 / C.rho0, eb = C.fxe1 + C.lam1 / C.rho1;
+    if (lane == 0) cost_piece += 0.5 * (C.rho0 * (ea * ea) + C.rho1 * (eb * eb));
+    chain0x = C.rho0 * ea;
+    chain0y = C.rho1 * eb;
+  }
+  double penalty_cost = wave_sum(cost_pen + cost_piece);
+  // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
+  const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
+  __syncthreads();
+
+  // =========================== sweep 2: backward, XY-gradient chain ===========================
+  if (!bad) {
+    double rcarryx = chain0x, rcarryy = chain0y;
+    for (int pass = npass - 1; pass >= 0; pass--) {
+      const int e = pass * 64 + lane;
+      const bool act = e < NE;
+      const int i = act ? e / TOPAY_EP : N - 1;
+      const int m = act ? e - TOPAY_EP * i : 0;
+      const int j = 2 * m;
+      double chx_in, chy_in, chx_ex, chy_ex;  // chain at the even sample / at the odd sample after it
+      if (STAGE == 2) {
+        const double gx = act ? gxy[2 * e] : 0.0, gy = act ? gxy[2 * e + 1] : 0.0;
+        const double sx_ = wave_incl_rscan(gx, lane), sy_ = wave_incl_rscan(gy, lane);
+        chx_in = sx_ + rcarryx; chy_in = sy_ + rcarryy;
+        chx_ex = chx_in - gx;   chy_ex = chy_in - gy;
+        rcarryx += __shfl(sx_, 0);
+        rcarryy += __shfl(sy_, 0);
+      } else {
+        // stage 1: chain of piece i = sum of tracking gradients of pieces > i (head(i*(2K+1)) quirk)
+        double sx_ = 0.0, sy_ = 0.0;
+        for (int ii = i + 1; ii < N; ii++) { sx_ += C.pcs[2 * ii]; sy_ += C.pcs[2 * ii + 1]; }
+        chx_in = chx_ex = sx_;
+        chy_in = chy_ex = sy_;
+      }
+      double v0 = 0, v1 = 0, v2 = 0, v3 = 0, vT = 0;
+      if (act) {
+        const double T1 = C.Tp[i];
+        const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
+        const int int_6K = TOPAY_K * 6;
+#pragma unroll
+        for (int odd = 0; odd < 2; odd++) {
+          if (odd == 1 && m == TOPAY_K) break;
+          const int jj = j + odd;
+          Basis B;
+          make_basis(jj * half, B);
+          double th0, th1, th2, s0, sd1, sd2;
+          poly3(cL, rows, i, 0, B, th0, th1, th2);
+          poly3(cL, rows, i, 1, B, s0, sd1, sd2);
+          double sn, cn;
+          det_sincos(th0, &sn, &cn);
+          const double alpha = 1.0 / (2 * TOPAY_K) * jj;
+          const double W = odd ? 4.0 : ((jj == 0 || jj == 2 * TOPAY_K) ? 1.0 : 2.0);  // IntegralChainCoeff
+          const double Cx = (odd ? chx_ex : chx_in) * W, Cy = (odd ? chy_ex : chy_in) * W;
+          // Single{X,Y}Grad{CTheta,CArc,T} — moma_traj_opt.cpp:1293-1300 / 1734-1740, x coeff 1744-1748
+          const double aTh = (-sd1 * sn * coeff) * Cx + (sd1 * cn * coeff) * Cy;
+          const double aS = (cn * coeff) * Cx + (sn * coeff) * Cy;
+          const double gTx = (sd2 * cn - sd1 * th1 * sn) * alpha * coeff + sd1 * cn / int_6K;
+          const double gTy = (sd2 * sn + sd1 * th1 * cn) * alpha * coeff + sd1 * sn / int_6K;
+          vT += gTx * Cx + gTy * Cy;
+          if (odd) { v2 = aTh; v3 = aS; } else { v0 = aTh; v1 = aS; }
+        }
+      }
+      pbuf[0 * 64 + lane] = v0; pbuf[1 * 64 + lane] = v1; pbuf[2 * 64 + lane] = v2; pbuf[3 * 64 + lane] = v3;
+      pbuf[4 * 64 + lane] = vT;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) {
+        if (ract[r]) {
+          const int pi = rpiece[r];
+          const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+          const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+          double gt = 0.0;
+          for (int ee = e_lo; ee < e_hi; ee++) {
+            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+            double b0, b1, b2, o0, o1, o2;
+            basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
+            basis_k(rk[r], (2 * mm + 1) * hs, o0, o1, o2);
+            acc[r][0] += b0 * pbuf[0 * 64 + l] + o0 * pbuf[2 * 64 + l];
+            acc[r][1] += b1 * pbuf[1 * 64 + l] + o1 * pbuf[3 * 64 + l];
+            gt += pbuf[4 * 64 + l];
+          }
+          if (rk[r] == 0) C.gdT[pi] += gt;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    penalty_cost = 1.0e+22;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++)
+#pragma unroll
+      for (int d = 0; d < 9; d++) acc[r][d] = 0.0;
+    if (lane < N) C.gdT[lane] = 0.0;
+    __syncthreads();
+  }
+
+  // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
+  double* band = C.X;
+  double* rdiag = C.X + 13 * rows;
+  double* adj = C.X + 14 * rows;  // [9][rows]
+  for (int t = lane; t < 14 * rows; t += 64) C.X[t] = C.lu[t];
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    if (ract[r]) {
+      const int pi = rpiece[r], k = rk[r];
+      const double T1 = C.Tp[pi], T2 = C.Tp[N + pi], T3 = C.Tp[2 * N + pi], T4 = C.Tp[3 * N + pi], T5 = C.Tp[4 * N + pi];
+#pragma unroll
+      for (int d = 0; d < 9; d++) {
+        double jg = 0.0;
+        if (k >= 3) {
+          const double c3 = cL[d * rows + 6 * pi + 3], c4 = cL[d * rows + 6 * pi + 4], c5 = cL[d * rows + 6 * pi + 5];
+          const double e = P.energy_weights[d];
+          if (k == 5) jg = 240.0 * c3 * e * T3 + 720.0 * c4 * e * T4 + 1440.0 * c5 * e * T5;
+          else if (k == 4) jg = 144.0 * c3 * e * T2 + 384.0 * c4 * e * T3 + 720.0 * c5 * e * T4;
+          else jg = 72.0 * c3 * e * T1 + 144.0 * c4 * e * T2 + 240.0 * c5 * e * T3;
+        }
+        adj[d * rows + rrow[r]] = jg + acc[r][d];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
+    for (int j = 0; j < rows; j++) {  // b(j) /= A(j,j); b(i) -= A(j,i) b(j), i = j+1..j+6
+      const int i = j + t;
+      if (lane < 54 && i < rows) adj[d * rows + i] -= BAND(j, i) * (adj[d * rows + j] * rdiag[j]);
+      __syncthreads();
+    }
+    for (int tt = lane; tt < 9 * rows; tt += 64) adj[tt] *= rdiag[tt % rows];
+    __syncthreads();
+    for (int j = rows - 1; j >= 0; j--) {  // b(i) -= A(j,i) b(j), i = j-6..j-1
+      const int i = j - t;
+      if (lane < 54 && i >= 0) adj[d * rows + i] -= BAND(j, i) * adj[d * rows + j];
+      __syncthreads();
+    }
+  }
+  // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
+  // each row lane forms its row's dot product, partial sums per piece go through rdiag[] (free now)
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    if (ract[r]) {
+      const int row = rrow[r];
+      // rows 6i+3..6i+8 belong to knot i (i < N-1); the last three rows to the tail condition
+      int pi, br;  // piece whose coefficients are used, B row
+      bool use = true;
+      if (row >= rows - 3) { pi = N - 1; br = 10 + (row - (rows - 3)); }  // B2: 10 vel, 11 acc, 12 jerk
+      else if (row < 3) { use = false; pi = 0; br = 0; }
+      else { pi = (row - 3) / 6; br = (row - 3) - 6 * pi; }
+      double part = 0.0;
+      if (use) {
+        const double T1 = C.Tp[pi], T2 = C.Tp[N + pi], T3 = C.Tp[2 * N + pi], T4 = C.Tp[3 * N + pi];
+#pragma unroll
+        for (int d = 0; d < 9; d++) {
+          const double* c = cL + d * rows + 6 * pi;
+          const double c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+          double b;
+          if (br == 0) b = -(24.0 * c4 + 120.0 * T1 * c5);                    // -snap
+          else if (br == 1) b = -120.0 * c5;                                  // -crackle
+          else if (br == 2 || br == 3 || br == 10) b = -(c1 + 2.0 * T1 * c2 + 3.0 * T2 * c3 + 4.0 * T3 * c4 + 5.0 * T4 * c5);
+          else if (br == 4 || br == 11) b = -(2.0 * c2 + 6.0 * T1 * c3 + 12.0 * T2 * c4 + 20.0 * T3 * c5);
+          else b = -(6.0 * c3 + 24.0 * T1 * c4 + 60.0 * T2 * c5);
+          part += b * adj[d * rows + row];
+        }
+      }
+      rdiag[row] = part;
+    }
+  }
+  __syncthreads();
+  double gdT_tot = 0.0;
+  if (lane < N) {
+    const int i = lane;
+    double s = 0.0;
+    if (i < N - 1) { for (int r = 0; r < 6; r++) s += rdiag[6 * i + 3 + r]; }
+    else { for (int r = 0; r < 3; r++) s += rdiag[rows - 3 + r]; }
+    gdT_tot = jerk_gdT + C.gdT[i] + s;
+  }
+  // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948
+  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
+  const double* Tau = C.x;
+  const double* Vq = C.x + 3 * N - 1;
+  double tsum = 0.0;
+  if (lane < N) {
+    C.g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
+    tsum = C.Tp[lane];
+  }
+  for (int t = lane; t < 9 * (N - 1); t += 64) {
+    const int i = t / 9, d = t - 9 * i;
+    const double gp = adj[d * rows + 6 * i + 5];  // gdP.col(i) = adjGrad.row(6i+5)
+    if (d == 0) C.g[N + i] = gp;
+    else if (d == 1) C.g[2 * N - 1 + i] = gp;
+    else C.g[3 * N - 1 + 7 * i + (d - 2)] = gp * dQdVq(Vq[7 * i + d - 2], P.joint_pos_limit_max[d - 2]);
+  }
+  if (lane == 0) C.g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
+  const double time_cost = wT * wave_sum(tsum);
+  __syncthreads();
+  return jerk_cost + penalty_cost + time_cost;
+}
+
+}  // namespace topay

@@ -1,0 +1,744 @@
+// libtopay_hip.so — kernels + host side of the C-ABI declared in include/topay.h.
+// gfx950 (MI355X) only; built by `hipcc --offload-arch=gfx950 -shared -fPIC`.  No torch types, no CPU fallback:
+// every entry point fails with TOPAY_ERR_NO_DEVICE when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "topay_solve.h"
+
+using namespace topay;
+
+#ifndef TOPAY_CPU_EMU
+extern __shared__ double topay_lds[];
+#define TOPAY_LDS_PTR topay_lds
+#else
+#define TOPAY_LDS_PTR ((double*)hip_emu::S().dyn_smem)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init(DevParams P, DevBatch Bt, const double* paths, const long long* path_off, const int* path_len,
+                       const double* bvel, const double* bacc, double* scratch, int scratch_stride, int maxN, int stride_n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bt.B) return;
+  init_one(P, paths + path_off[b] * 10, path_len[b], bvel + (size_t)b * 20, bacc + (size_t)b * 20,
+           scratch + (size_t)b * scratch_stride, maxN, Bt.N + b, Bt.s1_past + b, Bt.head + (size_t)b * 27,
+           Bt.tail + (size_t)b * 27, Bt.start_xy + 2 * b, Bt.goal_xy + 2 * b, Bt.init_xy + (size_t)b * 2 * maxN,
+           Bt.x0 + (size_t)b * stride_n);
+}
+
+__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int init_stride_N) {
+  C.lane = threadIdx.x;
+  C.N = Bt.N[b];
+  C.rows = 6 * C.N;
+  C.n = 10 * C.N - 8;
+  carve(C, TOPAY_LDS_PTR, Nmax_lds);
+  for (int t = C.lane; t < 27; t += 64) {
+    C.hp[t] = Bt.head[(size_t)b * 27 + t];
+    C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
+  }
+  C.lu = Bt.lu + (size_t)b * 14 * 6 * Bt.Nmax;
+  C.init_xy = Bt.init_xy + (size_t)b * 2 * init_stride_N;
+  C.sx = Bt.start_xy[2 * b]; C.sy = Bt.start_xy[2 * b + 1];
+  C.ex = Bt.goal_xy[2 * b];  C.ey = Bt.goal_xy[2 * b + 1];
+  C.fxe0 = 0.0; C.fxe1 = 0.0;
+}
+
+// test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
+template <int RMAX>
+__device__ __forceinline__ void eval_body(const DevParams& P, const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds,
+                                          int init_stride_N, int repeats) {
+  const int b = Bt.order[blockIdx.x];
+  EvalCtx C;
+  load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
+  const DevMap M = maps[Bt.map_id[b]];
+  C.x = Bt.x + (size_t)b * Bt.nmax;
+  C.g = Bt.work + (size_t)b * 4 * Bt.nmax;
+  C.lam0 = Bt.alm[4 * b]; C.lam1 = Bt.alm[4 * b + 1]; C.rho0 = Bt.alm[4 * b + 2]; C.rho1 = Bt.alm[4 * b + 3];
+  __syncthreads();
+  double f = 0.0;
+  for (int r = 0; r < repeats; r++) {
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, P, M);
+    else f = eval_cost_grad<2, RMAX>(C, P, M);
+  }
+  if (C.lane == 0) {
+    Bt.fout[b] = f;
+    Bt.xyerr[2 * b] = C.fxe0;
+    Bt.xyerr[2 * b + 1] = C.fxe1;
+  }
+}
+
+template <int RMAX>
+__device__ __forceinline__ void solve_body(const DevParams& P, const DevBatch& Bt, const DevMap* maps, int Nmax_lds,
+                                           int init_stride_N) {
+  const int b = Bt.order[blockIdx.x];
+  EvalCtx C;
+  load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
+  const DevMap M = maps[Bt.map_id[b]];
+  double* pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8]
+  SolveIO S;
+  S.x = Bt.x + (size_t)b * Bt.nmax;
+  S.g = Bt.work + ((size_t)b * 4 + 0) * Bt.nmax;
+  S.xp = Bt.work + ((size_t)b * 4 + 1) * Bt.nmax;
+  S.gp = Bt.work + ((size_t)b * 4 + 2) * Bt.nmax;
+  S.d = Bt.work + ((size_t)b * 4 + 3) * Bt.nmax;
+  S.hist_s = Bt.hist_s + (size_t)b * Bt.hist_m * Bt.nmax;
+  S.hist_y = Bt.hist_y + (size_t)b * Bt.hist_m * Bt.nmax;
+  S.hist_ys = Bt.hist_ys + (size_t)b * Bt.hist_m;
+  S.hist_al = Bt.hist_alpha + (size_t)b * Bt.hist_m;
+  S.nstride = Bt.nmax;
+  S.stats = Bt.stats + (size_t)b * 8;
+  S.trace = Bt.trace ? Bt.trace + (size_t)b * Bt.trace_cap : nullptr;
+  S.trace_cap = Bt.trace_cap;
+  // x <- x0
+  {
+    const double* x0 = Bt.x0 + (size_t)b * (10 * init_stride_N - 8);
+    for (int e = C.lane; e < C.n; e += 64) S.x[e] = x0[e];
+  }
+  int success = 0;
+  double cost = 0.0;
+  solve_trajectory<RMAX>(C, P, M, S, Bt.s1_past[b], pf, success, cost);
+  // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
+  __syncthreads();
+  const int N = C.N, rows = C.rows;
+  double* coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
+  for (int t = C.lane; t < 9 * rows; t += 64) coef[t] = C.cL[t];
+  if (C.lane < N) Bt.T[(size_t)b * Bt.Nmax + C.lane] = C.Tp[C.lane];
+  double* kn = Bt.knots + (size_t)b * 2 * (Bt.Nmax + 1);
+  if (C.lane == 0) { kn[0] = C.sx; kn[1] = C.sy; }
+  for (int t = C.lane; t < 2 * N; t += 64) kn[2 + t] = C.pcs[2 * N + 2 + t];
+  if (C.lane == 0) {
+    Bt.success[b] = success;
+    Bt.cost[b] = cost;
+    Bt.xyerr[2 * b] = C.fxe0;
+    Bt.xyerr[2 * b + 1] = C.fxe1;
+    Bt.alm[4 * b] = C.lam0; Bt.alm[4 * b + 1] = C.lam1; Bt.alm[4 * b + 2] = C.rho0; Bt.alm[4 * b + 3] = C.rho1;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_solve1(DevParams P, DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<1>(P, Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+__global__ void __launch_bounds__(64) k_solve2(DevParams P, DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<2>(P, Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+__global__ void __launch_bounds__(64) k_eval1(DevParams P, DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<1>(P, Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+}
+__global__ void __launch_bounds__(64) k_eval2(DevParams P, DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<2>(P, Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+}
+
+// test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
+__global__ void k_math(const double* a, const double* b, double* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  det_sincos(a[i], &s, &c);
+  out[4 * i] = s;
+  out[4 * i + 1] = c;
+  out[4 * i + 2] = det_atan2(a[i], b[i]);
+  out[4 * i + 3] = sqrt(fabs(a[i])) / (1.0 + fabs(b[i]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static void set_err(const std::string& s) { g_err = s; }
+#define HIPCHK(call)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      set_err(std::string(#call) + ": " + hipGetErrorString(e_));                                \
+      return TOPAY_ERR_NO_DEVICE;                                                                \
+    }                                                                                            \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  topay_status ensure(size_t n) {
+    if (n <= bytes) return TOPAY_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    HIPCHK(hipMalloc(&p, n));
+    bytes = n;
+    return TOPAY_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+struct topay_ctx {
+  int device = 0;
+  topay_params_t hp;
+  DevParams dp;
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // maps
+  std::vector<DevMap> hmaps = std::vector<DevMap>(TOPAY_MAX_MAPS);
+  std::vector<DevBuf> map2d = std::vector<DevBuf>(TOPAY_MAX_MAPS), map3d = std::vector<DevBuf>(TOPAY_MAX_MAPS);
+  DevBuf dmaps;
+  std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
+  // batch
+  int B = 0, Nmax = 0, nmax = 0, total_states = 0, Pmax = 0;
+  std::vector<int> hN, order1, order2;  // per-trajectory N; launch orders of the two row classes
+  DevBuf paths, path_off, path_len, bvel, bacc, scratch;
+  DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
+  DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace;
+  int trace_cap = 0;
+  DevBatch db;
+  bool have_traj = false, solved = false;
+  double last_ms = 0.0;
+  int last_launches = 0;
+};
+
+static void make_dev_params(const topay_params_t& p, DevParams& d) {
+  memset(&d, 0, sizeof(d));
+  d.relu_mu = p.relu_mu;
+  for (int i = 0; i < 9; i++) d.energy_weights[i] = p.energy_weights[i];
+  d.s1_time_weight = p.s1_time_weight; d.s1_moment_weight = p.s1_moment_weight; d.s1_acc_weight = p.s1_acc_weight;
+  d.s1_domega_weight = p.s1_domega_weight; d.s1_path_pos_weight = p.s1_path_pos_weight;
+  d.s2_time_weight = p.s2_time_weight; d.s2_moment_weight = p.s2_moment_weight; d.s2_acc_weight = p.s2_acc_weight;
+  d.s2_domega_weight = p.s2_domega_weight; d.s2_collision_weight = p.s2_collision_weight;
+  d.s2_mani_colli_weight = p.s2_mani_colli_weight; d.s2_self_colli_weight = p.s2_self_colli_weight;
+  d.s2_mani_pos_weight = p.s2_mani_pos_weight; d.s2_mani_vel_weight = p.s2_mani_vel_weight;
+  d.s2_mani_acc_weight = p.s2_mani_acc_weight; d.s2_mean_time_weight = p.s2_mean_time_weight;
+  for (int i = 0; i < 2; i++) {
+    d.alm_init_lambda[i] = p.alm_init_lambda[i]; d.alm_init_rho[i] = p.alm_init_rho[i];
+    d.alm_rho_max[i] = p.alm_rho_max[i]; d.alm_gamma[i] = p.alm_gamma[i];
+  }
+  d.alm_tolerance = p.alm_tolerance;
+  d.alm_max_outer = p.alm_max_outer;
+  d.min_piece_num = p.min_piece_num;
+  d.sample_interval = p.sample_interval;
+  d.s1_normal_past = p.s1_normal_past; d.s1_shot_path_past = p.s1_shot_path_past;
+  d.s1_shot_path_horizon = p.s1_shot_path_horizon;
+  auto cp = [](const topay_lbfgs_params_t& a, DevLbfgs& b) {
+    b.mem_size = a.mem_size; b.past = a.past; b.max_iterations = a.max_iterations; b.max_linesearch = a.max_linesearch;
+    b.g_epsilon = a.g_epsilon; b.delta = a.delta; b.min_step = a.min_step; b.max_step = a.max_step;
+    b.f_dec_coeff = a.f_dec_coeff; b.s_curv_coeff = a.s_curv_coeff; b.cautious_factor = a.cautious_factor;
+    b.machine_prec = a.machine_prec;
+  };
+  cp(p.s1_lbfgs, d.s1_lbfgs);
+  cp(p.s2_lbfgs, d.s2_lbfgs);
+  d.chassis_height = p.chassis_height; d.chassis_colli_radius = p.chassis_colli_radius;
+  d.max_v = p.max_v; d.max_a = p.max_a; d.max_w = p.max_w; d.max_dw = p.max_dw;
+  for (int i = 0; i < 8; i++) d.colli_length[i] = p.colli_length[i];
+  int s = 0;
+  for (int i = 0; i < 16 && s < TOPAY_NSPH; i++)
+    if (p.colli_points[i] != 0.0) {  // moma_param.h:217-218
+      d.sph_off[s] = p.colli_points[i];
+      d.sph_r[s] = p.colli_point_radius[i];
+      s++;
+    }
+  for (int i = 0; i < 7; i++) {
+    d.joint_pos_limit_max[i] = p.joint_pos_limit_max[i];
+    d.joint_vel_limit[i] = p.joint_vel_limit[i];
+    d.joint_acc_limit[i] = p.joint_acc_limit[i];
+  }
+  for (int i = 0; i < 9; i++) d.relR[i] = p.relative_R[i];
+  for (int i = 0; i < 3; i++) d.relT[i] = p.relative_t[i];
+}
+
+static int sphere_layout_ok(const topay_params_t& p) {
+  // the kernels hard-wire MomaParam's sphere-per-link layout {2,1,2,1,2,1,2,1}
+  const int want[8] = {2, 1, 2, 1, 2, 1, 2, 1};
+  for (int i = 0; i < 8; i++) {
+    int c = (p.colli_points[2 * i] != 0.0) + (p.colli_points[2 * i + 1] != 0.0);
+    if (c != want[i]) return 0;
+    if (want[i] == 1 && p.colli_points[2 * i] != 0.0) return 0;
+  }
+  return 1;
+}
+
+extern "C" {
+
+const char* topay_last_error(void) { return g_err.c_str(); }
+
+topay_status topay_default_params(topay_params_t* p) {
+  if (!p) return TOPAY_ERR_INVALID_ARG;
+  memset(p, 0, sizeof(*p));
+  // src/planner/params/optimizer.yaml
+  p->int_K = 12; p->min_piece_num = 3; p->relu_mu = 1.0e-3; p->sample_interval = 1.5;
+  const double ew[9] = {0.33, 1, 1, 1, 1, 1, 1, 1, 1};
+  for (int i = 0; i < 9; i++) p->energy_weights[i] = ew[i];
+  p->s1_time_weight = 20.0; p->s1_moment_weight = 1000.0; p->s1_acc_weight = 1000.0; p->s1_domega_weight = 1000.0;
+  p->s1_path_pos_weight = 200000.0; p->s1_normal_past = 2; p->s1_shot_path_past = 8; p->s1_shot_path_horizon = 0.5;
+  auto lb = [](topay_lbfgs_params_t& l) {  // lbfgs.hpp:15-129 defaults
+    l.mem_size = 8; l.g_epsilon = 1.0e-5; l.past = 3; l.delta = 1.0e-6; l.max_iterations = 0; l.max_linesearch = 64;
+    l.min_step = 1.0e-20; l.max_step = 1.0e+20; l.f_dec_coeff = 1.0e-4; l.s_curv_coeff = 0.9; l.cautious_factor = 1.0e-6;
+    l.machine_prec = 1.0e-16;
+  };
+  lb(p->s1_lbfgs); lb(p->s2_lbfgs);
+  p->s1_lbfgs.mem_size = 256; p->s1_lbfgs.g_epsilon = 0.0; p->s1_lbfgs.min_step = 0.0; p->s1_lbfgs.delta = 1.0e-2;
+  p->s1_lbfgs.max_iterations = 8000; p->s1_lbfgs.past = 2;
+  p->s2_lbfgs.mem_size = 256; p->s2_lbfgs.past = 3; p->s2_lbfgs.g_epsilon = 0.0; p->s2_lbfgs.min_step = 1.0e-32;
+  p->s2_lbfgs.delta = 1.0e-4; p->s2_lbfgs.max_iterations = 8000;
+  p->s2_time_weight = 50.0; p->s2_moment_weight = 300.0; p->s2_acc_weight = 3000.0; p->s2_domega_weight = 3000.0;
+  p->s2_collision_weight = 500000.0; p->s2_mani_colli_weight = 500000.0; p->s2_self_colli_weight = 500000.0;
+  p->s2_mani_pos_weight = 500.0; p->s2_mani_vel_weight = 500.0; p->s2_mani_acc_weight = 500.0;
+  p->s2_mean_time_weight = 5000.0;
+  for (int i = 0; i < 2; i++) {
+    p->alm_init_lambda[i] = 0.0; p->alm_init_rho[i] = 1.0e4; p->alm_rho_max[i] = 1.0e10; p->alm_gamma[i] = 9.0;
+  }
+  p->alm_tolerance = 0.01;
+  p->alm_max_outer = 30;
+  // src/simulator/fake_moma/include/fake_moma/moma_param.h:36-126
+  p->chassis_height = 0.155; p->chassis_colli_radius = 0.4;
+  p->max_v = 1.0; p->max_a = 0.8; p->max_w = 1.25; p->max_dw = 1.0;
+  const double cl[8] = {0.139, 0.1015, 0.1525, 0.1035, 0.1285, 0.0815, 0.144, 0.05};
+  const double cp[16] = {0.139 - 0.09, 0.139, 0.0, 0.1015, 0.1525 - 0.08, 0.1525, 0.0, 0.1035,
+                         0.1285 - 0.07, 0.1285, 0.0, 0.0815, 0.144 - 0.07, 0.144, 0.0, 0.1};
+  const double cr[16] = {0.06, 0.06, 0.0, 0.08, 0.04, 0.04, 0.0, 0.07, 0.035, 0.035, 0.0, 0.06, 0.035, 0.035, 0.0, 0.08};
+  for (int i = 0; i < 8; i++) p->colli_length[i] = cl[i];
+  for (int i = 0; i < 16; i++) {
+    p->colli_points[i] = cp[i];
+    p->colli_point_radius[i] = (cr[i] > 1e-4 && cr[i] < 0.055) ? 0.055 : cr[i];  // moma_param.h:110-112
+  }
+  const double qm[7] = {3.1, 2.26, 3.1, 2.355, 3.1, 2.23, 6.28};
+  for (int i = 0; i < 7; i++) { p->joint_pos_limit_max[i] = qm[i]; p->joint_vel_limit[i] = 2.35; p->joint_acc_limit[i] = 6.28; }
+  const double rr[9] = {0.7071068, 0.7071068, 0.0, -0.7071068, 0.7071068, 0.0, 0.0, 0.0, 1.0};
+  for (int i = 0; i < 9; i++) p->relative_R[i] = rr[i];
+  p->relative_t[0] = 0.0; p->relative_t[1] = 0.115; p->relative_t[2] = 0.016;
+  return TOPAY_OK;
+}
+
+topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out) {
+  if (!params || !out) return TOPAY_ERR_INVALID_ARG;
+  if (params->int_K != TOPAY_K) { set_err("int_K must be 12 in this build"); return TOPAY_ERR_UNSUPPORTED; }
+  if (!sphere_layout_ok(*params)) { set_err("unsupported collision sphere layout"); return TOPAY_ERR_UNSUPPORTED; }
+  if (params->s1_lbfgs.mem_size <= 0 || params->s2_lbfgs.mem_size <= 0 || params->s1_lbfgs.past > 8 ||
+      params->s2_lbfgs.past > 8 || params->s1_shot_path_past > 8 || params->s1_normal_past > 8) {
+    set_err("lbfgs mem_size must be > 0 and past <= 8");
+    return TOPAY_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err("no HIP device available: the MI355X HIP path is required (there is no CPU fallback)");
+    return TOPAY_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_err("device index out of range"); return TOPAY_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(device));
+  topay_ctx* c = new topay_ctx();
+  c->device = device;
+  c->hp = *params;
+  make_dev_params(*params, c->dp);
+  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipStreamCreate(&c->stream2));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+  if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
+  memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
+  *out = c;
+  return TOPAY_OK;
+}
+
+void topay_destroy(topay_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
+                    &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
+                    &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace};
+  for (DevBuf* b : bufs) b->release();
+  for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  delete c;
+}
+
+topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* desc, const double* esdf2d, const double* esdf3d) {
+  if (!c || !desc || !esdf2d || !esdf3d || map_id < 0 || map_id >= TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n2 = (size_t)desc->dims[0] * desc->dims[1], n3 = n2 * desc->dims[2];
+  if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
+  topay_status s;
+  if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
+  if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
+  HIPCHK(hipMemcpy(c->map2d[map_id].p, esdf2d, n2 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->map3d[map_id].p, esdf3d, n3 * 8, hipMemcpyHostToDevice));
+  DevMap& m = c->hmaps[map_id];
+  for (int i = 0; i < 3; i++) {
+    m.origin[i] = desc->origin[i]; m.dims[i] = desc->dims[i];
+    m.min_b[i] = desc->min_boundary[i]; m.max_b[i] = desc->max_boundary[i];
+  }
+  m.res = desc->resolution;
+  m.res_inv = 1.0 / desc->resolution;  // grid_map.cpp:41
+  m.esdf2d = c->map2d[map_id].as<double>();
+  m.esdf3d = c->map3d[map_id].as<double>();
+  c->have_map[map_id] = 1;
+  HIPCHK(hipMemcpy((char*)c->dmaps.p + sizeof(DevMap) * map_id, &c->hmaps[map_id], sizeof(DevMap), hipMemcpyHostToDevice));
+  return TOPAY_OK;
+}
+
+static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8) * sizeof(double); }
+
+static topay_status run_init(topay_ctx* c) {
+  const int B = c->B;
+  const int scratch_stride = (3 * c->Pmax + 1 + TOPAY_MAX_N) * ND;
+  hipLaunchKernelGGL(k_init, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, c->db, c->paths.as<double>(),
+                     c->path_off.as<long long>(), c->path_len.as<int>(), c->bvel.as<double>(), c->bacc.as<double>(),
+                     c->scratch.as<double>(), scratch_stride, TOPAY_MAX_N, 10 * TOPAY_MAX_N - 8);
+  HIPCHK(hipGetLastError());
+  return TOPAY_OK;
+}
+
+topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, const double* init_paths,
+                                 const double* boundary_vel, const double* boundary_acc, const int* map_ids) {
+  if (!c || batch <= 0 || !path_len || !init_paths) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  c->have_traj = false;
+  c->solved = false;
+  std::vector<long long> off(batch + 1, 0);
+  int Pmax = 0;
+  for (int b = 0; b < batch; b++) {
+    if (path_len[b] < 2) { set_err("every init path needs at least 2 states"); return TOPAY_ERR_INVALID_ARG; }
+    off[b + 1] = off[b] + path_len[b];
+    Pmax = std::max(Pmax, path_len[b]);
+  }
+  std::vector<int> mids(batch, 0);
+  for (int b = 0; b < batch; b++) {
+    if (map_ids) mids[b] = map_ids[b];
+    if (mids[b] < 0 || mids[b] >= TOPAY_MAX_MAPS || !c->have_map[mids[b]]) { set_err("map slot not set"); return TOPAY_ERR_NO_MAP; }
+  }
+  c->B = batch;
+  c->Pmax = Pmax;
+  const size_t tot = (size_t)off[batch];
+  topay_status s;
+#define ENS(buf, bytes) if ((s = c->buf.ensure(bytes)) != TOPAY_OK) return s
+  ENS(paths, tot * 10 * 8);
+  ENS(path_off, (size_t)(batch + 1) * 8);
+  ENS(path_len, (size_t)batch * 4);
+  ENS(bvel, (size_t)batch * 20 * 8);
+  ENS(bacc, (size_t)batch * 20 * 8);
+  ENS(scratch, (size_t)batch * (3 * Pmax + 1 + TOPAY_MAX_N) * ND * 8);
+  ENS(N, (size_t)batch * 4);
+  ENS(s1_past, (size_t)batch * 4);
+  ENS(map_id, (size_t)batch * 4);
+  ENS(head, (size_t)batch * 27 * 8);
+  ENS(tail, (size_t)batch * 27 * 8);
+  ENS(start_xy, (size_t)batch * 2 * 8);
+  ENS(goal_xy, (size_t)batch * 2 * 8);
+  ENS(init_xy, (size_t)batch * 2 * TOPAY_MAX_N * 8);
+  ENS(x0, (size_t)batch * (10 * TOPAY_MAX_N - 8) * 8);
+  ENS(order, (size_t)batch * 4);
+  HIPCHK(hipMemcpy(c->paths.p, init_paths, tot * 10 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->path_off.p, off.data(), (size_t)(batch + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->path_len.p, path_len, (size_t)batch * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->map_id.p, mids.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+  if (boundary_vel) HIPCHK(hipMemcpy(c->bvel.p, boundary_vel, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(c->bvel.p, 0, (size_t)batch * 20 * 8));
+  if (boundary_acc) HIPCHK(hipMemcpy(c->bacc.p, boundary_acc, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(c->bacc.p, 0, (size_t)batch * 20 * 8));
+  DevBatch& d = c->db;
+  memset(&d, 0, sizeof(d));
+  d.B = batch;
+  d.N = c->N.as<int>(); d.s1_past = c->s1_past.as<int>(); d.map_id = c->map_id.as<int>();
+  d.head = c->head.as<double>(); d.tail = c->tail.as<double>();
+  d.start_xy = c->start_xy.as<double>(); d.goal_xy = c->goal_xy.as<double>();
+  d.init_xy = c->init_xy.as<double>(); d.x0 = c->x0.as<double>();
+  d.order = c->order.as<int>();
+  if ((s = run_init(c)) != TOPAY_OK) return s;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->hN.assign(batch, 0);
+  HIPCHK(hipMemcpy(c->hN.data(), c->N.p, (size_t)batch * 4, hipMemcpyDeviceToHost));
+  int Nmax = 0;
+  for (int b = 0; b < batch; b++) {
+    if (c->hN[b] <= 0) { set_err("a trajectory needs more pieces than TOPAY_MAX_N"); return TOPAY_ERR_TOO_MANY_PIECES; }
+    Nmax = std::max(Nmax, c->hN[b]);
+  }
+  c->Nmax = Nmax;
+  c->nmax = 10 * Nmax - 8;
+  const int m = std::max(c->hp.s1_lbfgs.mem_size, c->hp.s2_lbfgs.mem_size);
+  // launch order: longest trajectories first inside each row class (tail latency)
+  std::vector<int> idx(batch);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) { return c->hN[a] > c->hN[b2]; });
+  c->order1.clear();
+  c->order2.clear();
+  for (int b : idx) (c->hN[b] <= 10 ? c->order1 : c->order2).push_back(b);
+  std::vector<int> ord(c->order2);
+  ord.insert(ord.end(), c->order1.begin(), c->order1.end());
+  HIPCHK(hipMemcpy(c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+  ENS(x, (size_t)batch * c->nmax * 8);
+  ENS(work, (size_t)batch * 4 * c->nmax * 8);
+  ENS(hist_s, (size_t)batch * m * c->nmax * 8);
+  ENS(hist_y, (size_t)batch * m * c->nmax * 8);
+  ENS(hist_ys, (size_t)batch * m * 8);
+  ENS(hist_alpha, (size_t)batch * m * 8);
+  ENS(lu, (size_t)batch * 14 * 6 * Nmax * 8);
+  ENS(success, (size_t)batch * 4);
+  ENS(cost, (size_t)batch * 8);
+  ENS(stats, (size_t)batch * 8 * 4);
+  ENS(xyerr, (size_t)batch * 2 * 8);
+  ENS(coef, (size_t)batch * 9 * 6 * Nmax * 8);
+  ENS(T, (size_t)batch * Nmax * 8);
+  ENS(knots, (size_t)batch * 2 * (Nmax + 1) * 8);
+  ENS(alm, (size_t)batch * 4 * 8);
+  ENS(fout, (size_t)batch * 8);
+#undef ENS
+  d.Nmax = Nmax; d.nmax = c->nmax; d.hist_m = m;
+  d.x = c->x.as<double>(); d.work = c->work.as<double>();
+  d.hist_s = c->hist_s.as<double>(); d.hist_y = c->hist_y.as<double>();
+  d.hist_ys = c->hist_ys.as<double>(); d.hist_alpha = c->hist_alpha.as<double>();
+  d.lu = c->lu.as<double>();
+  d.success = c->success.as<int>(); d.cost = c->cost.as<double>(); d.stats = c->stats.as<int>();
+  d.xyerr = c->xyerr.as<double>(); d.coef = c->coef.as<double>(); d.T = c->T.as<double>();
+  d.knots = c->knots.as<double>(); d.alm = c->alm.as<double>(); d.fout = c->fout.as<double>();
+  HIPCHK(hipMemset(c->success.p, 0, (size_t)batch * 4));
+  HIPCHK(hipMemset(c->stats.p, 0, (size_t)batch * 32));
+  c->have_traj = true;
+  return TOPAY_OK;
+}
+
+topay_status topay_reset(topay_ctx* c) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  c->solved = false;
+  return run_init(c);
+}
+
+}  // extern "C"
+
+template <typename KF1, typename KF2, typename... Args>
+static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, Args... args) {
+  // class 2 (11..21 pieces, two system rows per lane) first: the longest jobs
+  const int n2 = (int)c->order2.size(), n1 = (int)c->order1.size();
+  int launches = 0;
+  if (n2 > 0) {
+    int nm = 0;
+    for (int b : c->order2) nm = std::max(nm, c->hN[b]);
+    DevBatch d = c->db;
+    const size_t lds = solve_lds_bytes(nm);
+    HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k2, dim3(n2), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, args..., nm);
+    HIPCHK(hipGetLastError());
+    launches++;
+  }
+  if (n1 > 0) {
+    int nm = 0;
+    for (int b : c->order1) nm = std::max(nm, c->hN[b]);
+    DevBatch d = c->db;
+    d.order = c->db.order + n2;
+    const size_t lds = solve_lds_bytes(nm);
+    HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k1, dim3(n1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, args..., nm);
+    HIPCHK(hipGetLastError());
+    launches++;
+  }
+  c->last_launches = launches;
+  return TOPAY_OK;
+}
+
+extern "C" {
+
+topay_status topay_optimize(topay_ctx* c) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  topay_status s = launch_classes(c, k_solve1, k_solve2);
+  if (s != TOPAY_OK) return s;
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_ms = ms;
+  c->solved = true;
+  return TOPAY_OK;
+}
+
+topay_status topay_get_nmax(topay_ctx* c, int* nmax, int* Nmax) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (nmax) *nmax = c->nmax;
+  if (Nmax) *Nmax = c->Nmax;
+  return TOPAY_OK;
+}
+
+topay_status topay_get_batch(topay_ctx* c, int* success, double* cost, int* n_pieces) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  if (success) HIPCHK(hipMemcpy(success, c->success.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(hipMemcpy(cost, c->cost.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (n_pieces) memcpy(n_pieces, c->hN.data(), (size_t)c->B * 4);
+  return TOPAY_OK;
+}
+
+topay_status topay_get_stats(topay_ctx* c, int* stats) {
+  if (!c || !c->have_traj || !stats) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(stats, c->stats.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, int* n_pieces, double* durations,
+                              double* coeffs, double* knots_xy) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->hN[i], rows = 6 * N;
+  if (success) HIPCHK(hipMemcpy(success, c->success.as<int>() + i, 4, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(hipMemcpy(cost, c->cost.as<double>() + i, 8, hipMemcpyDeviceToHost));
+  if (n_pieces) *n_pieces = N;
+  if (durations) HIPCHK(hipMemcpy(durations, c->T.as<double>() + (size_t)i * c->Nmax, (size_t)N * 8, hipMemcpyDeviceToHost));
+  if (coeffs) {
+    std::vector<double> cm((size_t)9 * rows);
+    HIPCHK(hipMemcpy(cm.data(), c->coef.as<double>() + (size_t)i * 9 * 6 * c->Nmax, cm.size() * 8, hipMemcpyDeviceToHost));
+    // getTraj(): per piece the 6x9 block transposed, highest order first — minco.hpp:908-921
+    for (int p = 0; p < N; p++)
+      for (int d = 0; d < 9; d++)
+        for (int k = 0; k < 6; k++) coeffs[((size_t)p * 9 + d) * 6 + k] = cm[(size_t)d * rows + 6 * p + 5 - k];
+  }
+  if (knots_xy)
+    HIPCHK(hipMemcpy(knots_xy, c->knots.as<double>() + (size_t)i * 2 * (c->Nmax + 1), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const int nn = 10 * c->hN[i] - 8;
+  if (n) *n = nn;
+  if (x) {
+    // after optimize: the final iterate; before: the packed initial guess
+    if (c->solved) HIPCHK(hipMemcpy(x, c->x.as<double>() + (size_t)i * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+    else HIPCHK(hipMemcpy(x, c->x0.as<double>() + (size_t)i * (10 * TOPAY_MAX_N - 8), (size_t)nn * 8, hipMemcpyDeviceToHost));
+  }
+  return TOPAY_OK;
+}
+
+topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
+                        double* f, double* g, double* final_xy_error) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B || (stage != 1 && stage != 2) || !x) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->hN[i], nn = 10 * N - 8;
+  HIPCHK(hipMemcpy(c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
+  double alm[4] = {alm_lambda ? alm_lambda[0] : c->hp.alm_init_lambda[0], alm_lambda ? alm_lambda[1] : c->hp.alm_init_lambda[1],
+                   alm_rho ? alm_rho[0] : c->hp.alm_init_rho[0], alm_rho ? alm_rho[1] : c->hp.alm_init_rho[1]};
+  HIPCHK(hipMemcpy(c->alm.as<double>() + (size_t)i * 4, alm, 32, hipMemcpyHostToDevice));
+  // single-block launch through a one-entry order array placed at the end of the order buffer
+  DevBuf tmp;
+  topay_status s = tmp.ensure(4);
+  if (s != TOPAY_OK) return s;
+  HIPCHK(hipMemcpy(tmp.p, &i, 4, hipMemcpyHostToDevice));
+  DevBatch d = c->db;
+  d.order = tmp.as<int>();
+  const size_t lds = solve_lds_bytes(N);
+  if (N <= 10) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_eval1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_eval1, dim3(1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_eval2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_eval2, dim3(1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  tmp.release();
+  if (f) HIPCHK(hipMemcpy(f, c->fout.as<double>() + i, 8, hipMemcpyDeviceToHost));
+  if (g) HIPCHK(hipMemcpy(g, c->work.as<double>() + (size_t)i * 4 * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+  if (final_xy_error) HIPCHK(hipMemcpy(final_xy_error, c->xyerr.as<double>() + 2 * i, 16, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+// Batched hook: evaluate every candidate `repeats` times at its packed initial guess x0 (ALM state = initial).
+topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if ((stage != 1 && stage != 2) || repeats <= 0) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  // x <- x0 (strided copy), alm <- init
+  std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);
+  HIPCHK(hipMemcpy(x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));
+  for (int b = 0; b < c->B; b++) {
+    const int nn = 10 * c->hN[b] - 8;
+    memcpy(&xs[(size_t)b * c->nmax], &x0[(size_t)b * (10 * TOPAY_MAX_N - 8)], (size_t)nn * 8);
+    alm[4 * b] = c->hp.alm_init_lambda[0]; alm[4 * b + 1] = c->hp.alm_init_lambda[1];
+    alm[4 * b + 2] = c->hp.alm_init_rho[0]; alm[4 * b + 3] = c->hp.alm_init_rho[1];
+  }
+  HIPCHK(hipMemcpy(c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  topay_status s = launch_classes(c, k_eval1, k_eval2, stage, repeats);
+  if (s != TOPAY_OK) return s;
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_ms = ms;
+  if (f) HIPCHK(hipMemcpy(f, c->fout.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+topay_status topay_check_feasible(topay_ctx* c, int* feasible) {
+  (void)c; (void)feasible;
+  set_err("topay_check_feasible: not built yet (SURVEY.md section 8f rank 1)");
+  return TOPAY_ERR_UNSUPPORTED;
+}
+
+// Debug / parity tooling: record f of every evaluation of the next topay_optimize (cap per candidate; 0 = off).
+topay_status topay_set_trace(topay_ctx* c, int cap) {
+  if (!c || !c->have_traj || cap < 0) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  c->trace_cap = cap;
+  c->db.trace = nullptr;
+  c->db.trace_cap = 0;
+  if (cap > 0) {
+    topay_status s = c->trace.ensure((size_t)c->B * cap * 8);
+    if (s != TOPAY_OK) return s;
+    HIPCHK(hipMemset(c->trace.p, 0, (size_t)c->B * cap * 8));
+    c->db.trace = c->trace.as<double>();
+    c->db.trace_cap = cap;
+  }
+  return TOPAY_OK;
+}
+topay_status topay_get_trace(topay_ctx* c, int i, double* out) {
+  if (!c || !c->have_traj || c->trace_cap <= 0 || i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(out, c->trace.as<double>() + (size_t)i * c->trace_cap, (size_t)c->trace_cap * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+// Test hook: evaluate the deterministic sin/cos/atan2 (and an IEEE sqrt/div probe) on the device.
+topay_status topay_test_math(topay_ctx* c, int n, const double* a, const double* b, double* out4n) {
+  if (!c || n <= 0 || !a || !b || !out4n) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf da, dbb, dout;
+  topay_status s;
+  if ((s = da.ensure((size_t)n * 8)) != TOPAY_OK || (s = dbb.ensure((size_t)n * 8)) != TOPAY_OK ||
+      (s = dout.ensure((size_t)n * 32)) != TOPAY_OK)
+    return s;
+  HIPCHK(hipMemcpy(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dbb.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_math, dim3((n + 63) / 64), dim3(64), 0, c->stream, da.as<double>(), dbb.as<double>(), dout.as<double>(), n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  da.release(); dbb.release(); dout.release();
+  return TOPAY_OK;
+}
+
+topay_status topay_last_kernel_ms(topay_ctx* c, double* ms, int* launches) {
+  if (!c) return TOPAY_ERR_INVALID_ARG;
+  if (ms) *ms = c->last_ms;
+  if (launches) *launches = c->last_launches;
+  return TOPAY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+// Persistent one-wavefront-per-trajectory solver: stage-1 L-BFGS, stage-2 ALM loop of L-BFGS runs.
+//
+// Follows /root/reference/src/planner/src/moma_traj_opt.cpp:359-497 (optimize part of optimizeTraj) and
+// planner/include/utils/lbfgs.hpp:276-389 (line_search_lewisoverton), 439-722 (lbfgs_optimize), including the
+// reference's non-standard early accept (lbfgs.hpp:327-330), cautious update (675-677) and full-length
+// history (mem_size 256).  The 1.0 s wall-clock cap of the ALM loop (moma_traj_opt.cpp:403-407) is replaced
+// by the deterministic cap DevParams::alm_max_outer.
+//
+// The L-BFGS vectors x, g, xp, gp, d and the (s, y) history live in HBM, element e owned by lane e % 64;
+// dot products are wave reductions; the whole solve is one launch with a single evaluation call site.
+#pragma once
+#include "topay_eval.h"
+
+namespace topay {
+
+struct SolveIO {
+  double* x;       // [n] decision vector (in: x0, out: final)
+  double* g;       // [n]
+  double* xp;      // [n]
+  double* gp;      // [n]
+  double* d;       // [n]
+  double* hist_s;  // [m][nstride]
+  double* hist_y;  // [m][nstride]
+  double* hist_ys; // [m]
+  double* hist_al; // [m]
+  int nstride;
+  int* stats;      // [8]
+  double* trace;   // optional f-per-evaluation trace
+  int trace_cap;
+};
+
+__device__ __forceinline__ double vec_dot(const double* a, const double* b, int n, int lane) {
+  double s = 0.0;
+  for (int e = lane; e < n; e += 64) s += a[e] * b[e];
+  return wave_sum(s);
+}
+
+template <int RMAX>
+__device__ __forceinline__ void solve_trajectory(EvalCtx& C, const DevParams& P, const DevMap& M, SolveIO& S, int s1_past,
+                                                 double* pf /* LDS [8] */, int& success_out, double& cost_out) {
+  const int lane = C.lane, n = C.n;
+  int stage = 1;
+  int alm_iter = 0;
+  bool success = false;
+  int st_s1_ret = 0, st_s1_it = 0, st_s1_ev = 0, st_s2_ret = 0, st_s2_it = 0, st_s2_ev = 0, st_sumb = 0;
+  C.lam0 = P.alm_init_lambda[0]; C.lam1 = P.alm_init_lambda[1];
+  C.rho0 = P.alm_init_rho[0];    C.rho1 = P.alm_init_rho[1];
+  C.x = S.x;
+  C.g = S.g;
+
+  // per-run L-BFGS state (lbfgs.hpp:447-449)
+  int k = 0, end = 0, bound = 0, count = 0, ret = 0, evals = 0;
+  double fx = 0.0, step = 0.0, stp = 0.0, finit = 0.0, dginit = 0.0, dgtest = 0.0, dstest = 0.0, mu = 0.0, nu = 0.0;
+  bool brackt = false, touched = false;
+  enum { MODE_INIT = 0, MODE_LS = 1 };
+  int mode = MODE_INIT;
+  double cost = 0.0;
+  int ntrace = 0;
+
+  for (;;) {
+    const DevLbfgs& lp = stage == 1 ? P.s1_lbfgs : P.s2_lbfgs;
+    const int past = stage == 1 ? s1_past : lp.past;
+    const int mem = lp.mem_size;
+    // ------------------------------------------------------------------ evaluate at x
+    __syncthreads();
+    double f;
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, P, M);
+    else f = eval_cost_grad<2, RMAX>(C, P, M);
+    evals++;
+    if (S.trace && lane == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;
+    ntrace++;
+
+    enum { GO_EVAL = 0, GO_LS_BEGIN = 1, GO_RUN_END = 2 };
+    int go = GO_EVAL;
+    if (mode == MODE_INIT) {
+      // lbfgs.hpp:523-554
+      fx = f;
+      if (lane == 0) pf[0] = fx;
+      double gmax = 0.0, xmax = 0.0;
+      for (int e = lane; e < n; e += 64) {
+        const double ge = S.g[e];
+        S.d[e] = -ge;
+        gmax = fmax(gmax, fabs(ge));
+        xmax = fmax(xmax, fabs(S.x[e]));
+      }
+      gmax = wave_max(gmax);
+      xmax = wave_max(xmax);
+      k = 0;
+      if (gmax / fmax(1.0, xmax) < lp.g_epsilon) {
+        ret = TOPAY_LBFGS_CONVERGENCE;
+        go = GO_RUN_END;
+      } else {
+        step = 1.0 / sqrt(vec_dot(S.d, S.d, n, lane));
+        k = 1;
+        end = 0;
+        bound = 0;
+        go = GO_LS_BEGIN;
+      }
+    } else {
+      // ---- one line-search trial evaluated — lbfgs.hpp:318-387
+      ++count;
+      int ls = 0;  // 0: continue, >0: accepted with `count` evaluations, <0: error
+      if (isinf(f) || isnan(f)) {
+        ls = TOPAY_LBFGSERR_INVALID_FUNCVAL;
+      } else if (past > 0 && fabs(finit - f) / (fabs(finit) + 1.0) < lp.delta / past) {
+        ls = count;  // reference-specific early accept (lbfgs.hpp:327-330)
+      } else {
+        bool accepted = false;
+        if (f > finit + stp * dgtest) {
+          nu = stp;
+          brackt = true;
+        } else {
+          const double gs = vec_dot(S.g, S.d, n, lane);
+          if (gs < dstest) mu = stp;
+          else accepted = true;
+        }
+        if (accepted) ls = count;
+        else if (lp.max_linesearch <= count) ls = TOPAY_LBFGSERR_MAXIMUMLINESEARCH;
+        else if (brackt && (nu - mu) < lp.machine_prec * nu) ls = TOPAY_LBFGSERR_WIDTHTOOSMALL;
+        else {
+          if (brackt) stp = 0.5 * (mu + nu);
+          else stp *= 2.0;
+          if (stp < lp.min_step) ls = TOPAY_LBFGSERR_MINIMUMSTEP;
+          else if (stp > lp.max_step) {
+            if (touched) ls = TOPAY_LBFGSERR_MAXIMUMSTEP;
+            else { touched = true; stp = lp.max_step; }
+          }
+        }
+      }
+      if (ls == 0) {
+        for (int e = lane; e < n; e += 64) S.x[e] = S.xp[e] + stp * S.d[e];
+        go = GO_EVAL;
+      } else if (ls < 0) {
+        // revert to the previous point — lbfgs.hpp:575-582 (fx keeps the last trial value)
+        fx = f;
+        for (int e = lane; e < n; e += 64) { S.x[e] = S.xp[e]; S.g[e] = S.gp[e]; }
+        ret = ls;
+        go = GO_RUN_END;
+      } else {
+        // ---- iteration accepted — lbfgs.hpp:584-714
+        fx = f;
+        step = stp;
+        bool fin = false;
+        // progress callback earlyExit (moma_traj_opt.cpp:1873) cancels when k > max_iterations: never before 632
+        if (stage == 2 && k > lp.max_iterations) { ret = TOPAY_LBFGS_CANCELED; fin = true; }
+        if (!fin) {
+          double gmax = 0.0, xmax = 0.0;
+          for (int e = lane; e < n; e += 64) { gmax = fmax(gmax, fabs(S.g[e])); xmax = fmax(xmax, fabs(S.x[e])); }
+          gmax = wave_max(gmax);
+          xmax = wave_max(xmax);
+          if (gmax / fmax(1.0, xmax) < lp.g_epsilon) { ret = TOPAY_LBFGS_CONVERGENCE; fin = true; }
+        }
+        if (!fin && past > 0) {
+          if (past <= k) {
+            const double rate = fabs(pf[k % past] - fx) / fmax(1.0, fabs(fx));
+            if (rate < lp.delta) { ret = TOPAY_LBFGS_STOP; fin = true; }
+          }
+          if (!fin) {
+            __syncthreads();
+            if (lane == 0) pf[k % past] = fx;
+            __syncthreads();
+          }
+        }
+        if (!fin && lp.max_iterations != 0 && lp.max_iterations <= k) { ret = TOPAY_LBFGSERR_MAXIMUMITERATION; fin = true; }
+        if (fin) {
+          go = GO_RUN_END;
+        } else {
+          ++k;
+          // s = x - xp, y = g - gp; ys, yy, |s|^2, |gp|^2 — lbfgs.hpp:647-677
+          double* sE = S.hist_s + (size_t)end * S.nstride;
+          double* yE = S.hist_y + (size_t)end * S.nstride;
+          double ys = 0.0, yy = 0.0, ss = 0.0, gg = 0.0;
+          for (int e = lane; e < n; e += 64) {
+            const double se = S.x[e] - S.xp[e], ye = S.g[e] - S.gp[e], gpe = S.gp[e];
+            sE[e] = se;
+            yE[e] = ye;
+            ys += ye * se; yy += ye * ye; ss += se * se; gg += gpe * gpe;
+            S.d[e] = -S.g[e];
+          }
+          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gg = wave_sum(gg);
+          S.hist_ys[end] = ys;  // every lane stores the same value; each lane later reads its own store
+          const double cau = ss * sqrt(gg) * lp.cautious_factor;
+          if (ys > cau) {
+            ++bound;
+            bound = mem < bound ? mem : bound;
+            end = (end + 1) % mem;
+            if (stage == 2) st_sumb += bound;
+            int j = end;
+            for (int i = 0; i < bound; ++i) {
+              j = (j + mem - 1) % mem;
+              const double* sj = S.hist_s + (size_t)j * S.nstride;
+              const double* yj = S.hist_y + (size_t)j * S.nstride;
+              const double al = vec_dot(sj, S.d, n, lane) / S.hist_ys[j];
+              S.hist_al[j] = al;
+              for (int e = lane; e < n; e += 64) S.d[e] += (-al) * yj[e];
+            }
+            const double sc = ys / yy;
+            for (int e = lane; e < n; e += 64) S.d[e] *= sc;
+            for (int i = 0; i < bound; ++i) {
+              const double* sj = S.hist_s + (size_t)j * S.nstride;
+              const double* yj = S.hist_y + (size_t)j * S.nstride;
+              const double beta = vec_dot(yj, S.d, n, lane) / S.hist_ys[j];
+              const double co = S.hist_al[j] - beta;
+              for (int e = lane; e < n; e += 64) S.d[e] += co * sj[e];
+              j = (j + 1) % mem;
+            }
+          }
+          step = 1.0;
+          go = GO_LS_BEGIN;
+        }
+      }
+    }
+
+    if (go == GO_LS_BEGIN) {
+      // lbfgs.hpp:559-573 + line-search prologue 288-311
+      for (int e = lane; e < n; e += 64) { S.xp[e] = S.x[e]; S.gp[e] = S.g[e]; }
+      stp = step;
+      count = 0;
+      brackt = false;
+      touched = false;
+      mu = 0.0;
+      nu = lp.max_step;
+      int err = 0;
+      if (!(stp > 0.0)) err = TOPAY_LBFGSERR_INVALIDPARAMETERS;
+      else {
+        dginit = vec_dot(S.gp, S.d, n, lane);
+        if (0.0 < dginit) err = TOPAY_LBFGSERR_INCREASEGRADIENT;
+      }
+      if (err) {
+        ret = err;  // x == xp, g == gp already
+        go = GO_RUN_END;
+      } else {
+        finit = fx;
+        dgtest = lp.f_dec_coeff * dginit;
+        dstest = lp.s_curv_coeff * dginit;
+        for (int e = lane; e < n; e += 64) S.x[e] = S.xp[e] + stp * S.d[e];
+        mode = MODE_LS;
+        go = GO_EVAL;
+      }
+    }
+
+    if (go == GO_RUN_END) {
+      cost = fx;
+      const bool okret = (ret == TOPAY_LBFGS_CONVERGENCE || ret == TOPAY_LBFGS_CANCELED || ret == TOPAY_LBFGS_STOP ||
+                          ret == TOPAY_LBFGSERR_MAXIMUMITERATION);
+      if (stage == 1) {
+        st_s1_ret = ret; st_s1_it = k; st_s1_ev = evals;
+        if (!okret) break;  // moma_traj_opt.cpp:370-374
+        stage = 2;
+        alm_iter = 0;
+      } else {
+        st_s2_ret = ret; st_s2_it += k; st_s2_ev += evals;
+        if (!(okret || ret == TOPAY_LBFGSERR_MAXIMUMLINESEARCH)) { success = false; break; }  // 429-441
+        const double en = sqrt(C.fxe0 * C.fxe0 + C.fxe1 * C.fxe1);
+        if (en < P.alm_tolerance) { success = true; break; }  // 451-455
+        C.lam0 += C.rho0 * C.fxe0;  // 456-459
+        C.lam1 += C.rho1 * C.fxe1;
+        C.rho0 = fmin((1 + P.alm_gamma[0]) * C.rho0, P.alm_rho_max[0]);
+        C.rho1 = fmin((1 + P.alm_gamma[1]) * C.rho1, P.alm_rho_max[1]);
+      }
+      if (alm_iter >= P.alm_max_outer) break;  // deterministic stand-in for the 1.0 s cap (403-407)
+      alm_iter++;
+      evals = 0;
+      mode = MODE_INIT;
+    }
+  }
+  if (lane == 0) {
+    S.stats[0] = st_s1_ret; S.stats[1] = st_s1_it; S.stats[2] = st_s1_ev; S.stats[3] = st_s2_ret;
+    S.stats[4] = st_s2_it; S.stats[5] = st_s2_ev; S.stats[6] = alm_iter; S.stats[7] = st_sumb;
+  }
+  success_out = success ? 1 : 0;
+  cost_out = cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// set_init_traj == optimizeTraj lines 146-357 (moma_traj_opt.cpp).  One thread per trajectory: the
+// resampling is short, sequential scalar work.  scratch: per trajectory (3*P+1) x 14 doubles.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void normalize_angle(double ref, double& a) {
+  const double PI = 3.14159265358979323846;
+  while (ref - a > PI) a += 2 * PI;
+  while (ref - a < -PI) a -= 2 * PI;
+}
+__device__ __forceinline__ double duration_trapezoid(double length, double startV, double endV, double maxV, double maxA) {
+  double startv2 = startV * startV, endv2 = endV * endV, maxv2 = maxV * maxV;
+  if (startV > maxV) startv2 = maxv2;
+  if (endV > maxV) endv2 = maxv2;
+  const double critical_len = (maxv2 - startv2) / (2 * maxA) + (maxv2 - endv2) / (2 * maxA);
+  if (length >= critical_len) return (maxV - startV) / maxA + (maxV - endV) / maxA + (length - critical_len) / maxV;
+  const double tmpv = sqrt(0.5 * (startv2 + endv2 + 2 * maxA * length));
+  return (tmpv - startV) / maxA + (tmpv - endV) / maxA;
+}
+__device__ __forceinline__ double arc_trapezoid(double curt, double locallength, double startV, double endV, double maxV,
+                                                double maxA) {
+  double startv2 = startV * startV, endv2 = endV * endV, maxv2 = maxV * maxV;
+  if (startV > maxV) startv2 = maxv2;
+  if (endV > maxV) endv2 = maxv2;
+  const double critical_len = (maxv2 - startv2) / (2 * maxA) + (maxv2 - endv2) / (2 * maxA);
+  if (locallength >= critical_len) {
+    const double t1 = (maxV - startV) / maxA;
+    const double t2 = t1 + (locallength - critical_len) / maxV;
+    if (curt <= t1) return startV * curt + 0.5 * maxA * (curt * curt);
+    else if (curt <= t2) return startV * t1 + 0.5 * maxA * (t1 * t1) + (curt - t1) * maxV;
+    else return startV * t1 + 0.5 * maxA * (t1 * t1) + (t2 - t1) * maxV + maxV * (curt - t2) -
+                0.5 * maxA * (curt - t2) * (curt - t2);
+  } else {
+    const double tmpv = sqrt(0.5 * (startv2 + endv2 + 2 * maxA * locallength));
+    const double tmpt = (tmpv - startV) / maxA;
+    if (curt <= tmpt) return startV * curt + 0.5 * maxA * (curt * curt);
+    else return startV * tmpt + 0.5 * maxA * (tmpt * tmpt) + tmpv * (curt - tmpt) - 0.5 * maxA * (curt - tmpt) * (curt - tmpt);
+  }
+}
+
+// node layout in scratch: [0..11] = x y theta dtheta darc q7 ; [12] path_arc ; [13] weighted_path_arc
+#define ND 14
+__device__ __forceinline__ void init_one(const DevParams& P, const double* path, int Plen, const double* bvel,
+                                         const double* bacc, double* nodes, int maxN, int* N_out, int* past_out,
+                                         double* head, double* tail, double* start_xy, double* goal_xy, double* init_xy,
+                                         double* x0) {
+  auto BV = [&](int r, int c) { return bvel[c * 10 + r]; };
+  auto BA = [&](int r, int c) { return bacc[c * 10 + r]; };
+  start_xy[0] = path[0]; start_xy[1] = path[1];
+  goal_xy[0] = path[(size_t)(Plen - 1) * 10]; goal_xy[1] = path[(size_t)(Plen - 1) * 10 + 1];
+  int cnt = 0;
+  auto push = [&](const double* s12) {
+    for (int q = 0; q < 12; q++) nodes[(size_t)cnt * ND + q] = s12[q];
+    cnt++;
+  };
+  double s12[12];
+  for (int q = 0; q < 12; q++) s12[q] = 0.0;
+  s12[0] = path[0]; s12[1] = path[1]; s12[2] = path[2];
+  for (int q = 0; q < 7; q++) s12[5 + q] = path[3 + q];
+  push(s12);
+  for (int i = 1; i < Plen; i++) {
+    const double* cur = path + (size_t)i * 10;
+    const double* prev = path + (size_t)(i - 1) * 10;
+    const double* back = nodes + (size_t)(cnt - 1) * ND;
+    for (int q = 0; q < 12; q++) s12[q] = 0.0;
+    const double dx = cur[0] - prev[0], dy = cur[1] - prev[1];
+    const double arc_len = sqrt(dx * dx + dy * dy);
+    double now_theta = cur[2];
+    normalize_angle(back[2], now_theta);
+    double theta_diff = now_theta - back[2];
+    if (fabs(theta_diff) > 1e-2) {
+      if (arc_len < 1e-2) {
+        s12[0] = cur[0]; s12[1] = cur[1]; s12[2] = now_theta; s12[3] = theta_diff; s12[4] = 0.0;
+        for (int q = 0; q < 7; q++) s12[5 + q] = cur[3 + q];
+        push(s12);
+      } else {
+        for (int q = 0; q < 12; q++) s12[q] = back[q];
+        double direct_theta = det_atan2(cur[1] - back[1], cur[0] - back[0]);
+        normalize_angle(back[2], direct_theta);
+        theta_diff = direct_theta - back[2];
+        s12[2] = direct_theta; s12[3] = theta_diff; s12[4] = 0.0;
+        push(s12);
+        s12[0] = cur[0]; s12[1] = cur[1]; s12[2] = direct_theta; s12[3] = 0.0; s12[4] = arc_len;
+        for (int q = 0; q < 7; q++) s12[5 + q] = cur[3 + q];
+        push(s12);
+        const double* back2 = nodes + (size_t)(cnt - 1) * ND;
+        normalize_angle(back2[2], now_theta);
+        theta_diff = now_theta - back2[2];
+        s12[2] = now_theta; s12[3] = theta_diff; s12[4] = 0.0;
+        push(s12);
+      }
+    } else if (arc_len > 1e-2) {
+      s12[0] = cur[0]; s12[1] = cur[1]; s12[2] = now_theta; s12[3] = 0.0; s12[4] = arc_len;
+      for (int q = 0; q < 7; q++) s12[5 + q] = cur[3 + q];
+      push(s12);
+    }
+  }
+  const int path_num = cnt;
+  double total_len = 0, wtotal = 0;
+  nodes[12] = 0.0; nodes[13] = 0.0;
+  for (int idx = 1; idx < path_num; idx++) {
+    double* nd = nodes + (size_t)idx * ND;
+    total_len += nd[4];
+    nd[12] = total_len;
+    wtotal += 0.2 * fabs(nd[3]) + 1.4 * fabs(nd[4]);
+    nd[13] = wtotal;
+  }
+  const double total_time = duration_trapezoid(wtotal, BV(0, 0), 0.0, P.max_v, P.max_a);
+  int np = (int)(total_time / P.sample_interval + 0.5);
+  if (np < P.min_piece_num) np = P.min_piece_num;
+  const double sample_interval = total_time / np;
+  // inner points — moma_traj_opt.cpp:247-277.  They are written straight into x0 (theta, s, Vq).
+  int now_idx = 1, ninner = 0;
+  // temporary inner storage: reuse x0 region?  store inner (9) + xy (2) per point in `nodes` tail (beyond path_num)
+  double* inner = nodes + (size_t)path_num * ND;  // [k][11]
+  for (double t = sample_interval; t < total_time - 1e-3; t += sample_interval) {
+    const double arc = arc_trapezoid(t, wtotal, BV(0, 0), 0.0, P.max_v, P.max_a);
+    for (int kk = now_idx; kk < path_num; kk++) {
+      const double* pn = nodes + (size_t)kk * ND;
+      const double* pp = nodes + (size_t)(kk - 1) * ND;
+      const double tmp_arc = pn[13];
+      if (tmp_arc >= arc) {
+        now_idx = kk;
+        const double l1 = tmp_arc - arc;
+        const double l = pn[13] - pp[13];
+        if (ninner < maxN - 1) {
+          double* o = inner + (size_t)ninner * 11;
+          o[0] = pp[2] + (l - l1) / l * (pn[3]);
+          o[1] = pp[12] + (l - l1) / l * (pn[4]);
+          for (int q = 0; q < 7; q++) o[2 + q] = pp[5 + q] + (l - l1) / l * (pn[5 + q] - pp[5 + q]);
+          o[9] = l1 / l * pp[0] + (l - l1) / l * (pn[0]);
+          o[10] = l1 / l * pp[1] + (l - l1) / l * (pn[1]);
+        }
+        ninner++;
+        break;
+      }
+    }
+  }
+  const int N = ninner + 1;
+  if (N > maxN) {  // not representable in this build: flagged, the solver skips it
+    *N_out = -N;
+    *past_out = 0;
+    return;
+  }
+  *N_out = N;
+  for (int i = 0; i < ninner; i++) {
+    init_xy[2 * i] = inner[(size_t)i * 11 + 9];
+    init_xy[2 * i + 1] = inner[(size_t)i * 11 + 10];
+  }
+  init_xy[2 * ninner] = goal_xy[0];
+  init_xy[2 * ninner + 1] = goal_xy[1];
+  // boundary PVA — moma_traj_opt.cpp:281-297
+  for (int q = 0; q < 27; q++) { head[q] = 0.0; tail[q] = 0.0; }
+  const double* n0 = nodes;
+  const double* nl = nodes + (size_t)(path_num - 1) * ND;
+  head[0 * 9 + 0] = n0[2];
+  head[1 * 9 + 0] = BV(1, 0);
+  head[2 * 9 + 0] = BA(1, 0);
+  head[1 * 9 + 1] = BV(0, 0);
+  head[2 * 9 + 1] = BA(0, 0);
+  for (int q = 0; q < 7; q++) {
+    head[0 * 9 + 2 + q] = n0[5 + q];
+    head[1 * 9 + 2 + q] = BV(3 + q, 0);
+    head[2 * 9 + 2 + q] = BA(3 + q, 0);
+  }
+  tail[0 * 9 + 0] = nl[2];
+  tail[0 * 9 + 1] = nl[12];
+  for (int q = 0; q < 7; q++) {
+    tail[0 * 9 + 2 + q] = nl[5 + q];
+    tail[1 * 9 + 2 + q] = BV(3 + q, 1);
+    tail[2 * 9 + 2 + q] = BA(3 + q, 1);
+  }
+  // packed decision vector — moma_traj_opt.cpp:324-344
+  double* Tau = x0;
+  double* Theta = x0 + N;
+  double* Arc = x0 + 2 * N - 1;
+  double* Vq = x0 + 3 * N - 1;
+  const double tau0 = logC2(sample_interval);
+  for (int i = 0; i < N - 1; i++) {
+    Tau[i] = tau0;
+    Theta[i] = inner[(size_t)i * 11 + 0];
+    Arc[i] = inner[(size_t)i * 11 + 1];
+    for (int q = 0; q < 7; q++) Vq[i * 7 + q] = invSigmoidC2(inner[(size_t)i * 11 + 2 + q], P.joint_pos_limit_max[q]);
+  }
+  Tau[N - 1] = tau0;
+  Arc[N - 1] = tail[0 * 9 + 1];
+  // short-path handling — moma_traj_opt.cpp:354-357
+  *past_out = (fabs(tail[0 * 9 + 1]) < P.s1_shot_path_horizon) ? P.s1_shot_path_past : P.s1_normal_past;
+}
+
+}  // namespace topay

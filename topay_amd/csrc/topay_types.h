@@ -1,0 +1,89 @@
+// Device-side parameter/descriptor PODs shared by the kernels and the host C-ABI layer.
+#pragma once
+#include "../../include/topay.h"
+
+#define TOPAY_K 12          // int_K: Simpson panels per piece (optimizer.yaml:3)
+#define TOPAY_SP 25         // samples per piece = 2K+1
+#define TOPAY_EP 13         // even ("full") samples per piece = K+1
+#define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
+#define TOPAY_MAX_N 21      // 6N <= 128 rows = 2 rows per lane
+#define TOPAY_WAVE 64
+
+struct DevMap {
+  double origin[3];
+  double res, res_inv;
+  double min_b[3], max_b[3];
+  int dims[3];
+  int pad;
+  const double* esdf2d;
+  const double* esdf3d;
+};
+
+struct DevLbfgs {
+  int mem_size, past, max_iterations, max_linesearch;
+  double g_epsilon, delta, min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
+};
+
+struct DevParams {
+  double relu_mu;
+  double energy_weights[9];
+  double s1_time_weight, s1_moment_weight, s1_acc_weight, s1_domega_weight, s1_path_pos_weight;
+  double s2_time_weight, s2_moment_weight, s2_acc_weight, s2_domega_weight;
+  double s2_collision_weight, s2_mani_colli_weight, s2_self_colli_weight;
+  double s2_mani_pos_weight, s2_mani_vel_weight, s2_mani_acc_weight, s2_mean_time_weight;
+  double alm_init_lambda[2], alm_init_rho[2], alm_rho_max[2], alm_gamma[2];
+  double alm_tolerance;
+  int alm_max_outer;
+  int min_piece_num;
+  double sample_interval;
+  int s1_normal_past, s1_shot_path_past;
+  double s1_shot_path_horizon;
+  DevLbfgs s1_lbfgs, s2_lbfgs;
+  // robot
+  double chassis_height, chassis_colli_radius;
+  double max_v, max_a, max_w, max_dw;
+  double colli_length[8];
+  double sph_off[TOPAY_NSPH];   // offset along the link z axis of each sphere
+  double sph_r[TOPAY_NSPH];     // radius of each sphere
+  double joint_pos_limit_max[7];
+  double joint_vel_limit[7];
+  double joint_acc_limit[7];
+  double relR[9];
+  double relT[3];
+};
+
+// Per-batch device arrays (structure of arrays; strides Nmax / nmax fixed per batch).
+struct DevBatch {
+  int B, Nmax, nmax, hist_m;
+  // inputs produced by the init kernel
+  int* N;             // [B] pieces
+  int* s1_past;       // [B]
+  int* map_id;        // [B]
+  double* head;       // [B][27]  9x3 col-major start PVA
+  double* tail;       // [B][27]
+  double* start_xy;   // [B][2]
+  double* goal_xy;    // [B][2]
+  double* init_xy;    // [B][Nmax][2]
+  double* x0;         // [B][nmax]  packed initial decision vector
+  // solver state
+  double* x;          // [B][nmax]
+  double* work;       // [B][4][nmax]  g, xp, gp, d
+  double* hist_s;     // [B][m][nmax]
+  double* hist_y;     // [B][m][nmax]
+  double* hist_ys;    // [B][m]
+  double* hist_alpha; // [B][m]
+  double* lu;         // [B][14*6*Nmax]  LU stash (band + reciprocal diagonal)
+  // outputs
+  int* success;       // [B]
+  double* cost;       // [B]
+  int* stats;         // [B][8]
+  double* xyerr;      // [B][2]
+  double* coef;       // [B][9*6*Nmax]  (6N x 9 col-major, stride 6N of the trajectory)
+  double* T;          // [B][Nmax]
+  double* knots;      // [B][(Nmax+1)*2]
+  double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
+  double* fout;       // [B] eval hook output
+  const int* order;   // [B] block -> trajectory map
+  double* trace;      // optional [B][trace_cap] f of every evaluation (debug / parity tooling), may be null
+  int trace_cap;
+};

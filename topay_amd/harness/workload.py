@@ -43,6 +43,16 @@ def lib():
         L.wl_sample_scenario.argtypes = [C.c_void_p, C.c_uint64, c_dp, c_dp]
         L.wl_whole_body_collision.argtypes = [C.c_void_p, c_dp]
         L.wl_init_paths.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, C.c_uint64, c_dp, C.c_int, c_ip]
+        L.wl_tables_batch_create.restype = C.c_void_p
+        L.wl_tables_batch_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_int]
+        L.wl_tables_batch_destroy.argtypes = [C.c_void_p]
+        L.wl_tables_batch_ntraj.argtypes = [C.c_void_p]
+        L.wl_tables_batch_nstates.argtypes = [C.c_void_p]
+        L.wl_tables_batch_nstates.restype = C.c_longlong
+        L.wl_tables_batch_get.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
+        L.wl_tables_batch_world.argtypes = [C.c_void_p, C.c_int]
+        L.wl_tables_batch_world.restype = C.c_void_p
         _LIB = L
     return _LIB
 
@@ -52,10 +62,16 @@ def _dp(a):
 
 
 class World:
-    def __init__(self, kind, seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, keepouts=None, nthreads=0):
+    def __init__(self, kind, seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, keepouts=None, nthreads=0,
+                 _borrowed=None):
         L = lib()
-        ko = np.zeros((0, 2)) if keepouts is None else np.ascontiguousarray(keepouts, dtype=np.float64).reshape(-1, 2)
-        self.h = C.c_void_p(L.wl_world_create(kind, seed, size_xy, size_z, res, cloud_res, ko.shape[0], _dp(ko), nthreads))
+        if _borrowed is not None:
+            self.h = C.c_void_p(_borrowed)
+            self._owned = False
+        else:
+            ko = np.zeros((0, 2)) if keepouts is None else np.ascontiguousarray(keepouts, dtype=np.float64).reshape(-1, 2)
+            self.h = C.c_void_p(L.wl_world_create(kind, seed, size_xy, size_z, res, cloud_res, ko.shape[0], _dp(ko), nthreads))
+            self._owned = True
         self.kind = kind
         self.size_xy = size_xy
         dims = np.zeros(3, dtype=np.int32)
@@ -72,7 +88,8 @@ class World:
 
     def close(self):
         if self.h:
-            lib().wl_world_destroy(self.h)
+            if self._owned:
+                lib().wl_world_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -161,3 +178,39 @@ def cuboids_batch(n_scenarios, n_cand, map_seed=42, base_seed=42, first_scenario
         scen += [made] * len(lens)
         made += 1
     return w, np.concatenate(all_lens), np.concatenate(all_paths), np.asarray(scen, dtype=np.int32)
+
+
+class TablesBatch:
+    """S 'tables' scenarios, one map each, n_cand candidates per scenario (benchmark_tables batch)."""
+
+    def __init__(self, n_scenarios, n_cand, base_seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, nthreads=0):
+        L = lib()
+        self.h = C.c_void_p(L.wl_tables_batch_create(n_scenarios, n_cand, base_seed, size_xy, size_z, res, cloud_res, nthreads))
+        nt = L.wl_tables_batch_ntraj(self.h)
+        ns = L.wl_tables_batch_nstates(self.h)
+        self.lens = np.zeros(nt, dtype=np.int32)
+        self.scen = np.zeros(nt, dtype=np.int32)
+        paths = np.zeros(ns * 10)
+        L.wl_tables_batch_get(self.h, self.lens.ctypes.data_as(c_ip), self.scen.ctypes.data_as(c_ip), _dp(paths))
+        self.paths = paths.reshape(ns, 10)
+        self.scenarios = sorted(set(self.scen.tolist()))
+        self._worlds = {}
+
+    def world(self, sidx):
+        if sidx not in self._worlds:
+            wp = lib().wl_tables_batch_world(self.h, sidx)
+            self._worlds[sidx] = World(TABLES, _borrowed=wp)
+        return self._worlds[sidx]
+
+    def close(self):
+        if self.h:
+            for w in self._worlds.values():
+                w.close()
+            lib().wl_tables_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,6 +1,8 @@
 // C entry points of the synthetic-workload harness (see workload.hpp).  Loaded through ctypes by
 // topay_amd/harness/workload.py; used by bench.py and tests to build identical inputs for the HIP
 // path and the oracle.
+#include <atomic>
+
 #include "workload.hpp"
 
 using namespace topay_wl;
@@ -85,5 +87,86 @@ void wl_edt(const char* occ2d, const char* occ3d, int nx, int ny, int nz, double
   std::memcpy(esdf2d, gm.esdf2d.data(), gm.esdf2d.size() * sizeof(double));
   std::memcpy(esdf3d, gm.esdf3d.data(), gm.esdf3d.size() * sizeof(double));
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Benchmark batch for the "tables" scene: S scenarios, each with its OWN map (the reference regenerates the
+// map every episode with 1x1 m keep-outs at start and goal, planner.cpp:514-521, grid_map.cpp:755-772),
+// n_cand candidate init paths per scenario.  Built by a thread pool; everything stays in the handle.
+// ---------------------------------------------------------------------------------------------
+struct TablesBatch {
+  std::vector<World*> worlds;
+  std::vector<std::array<double, 10>> starts, goals;
+  std::vector<int> lens;          // per trajectory
+  std::vector<int> scen;          // scenario of each trajectory
+  std::vector<double> paths;      // ragged
+};
+
+void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_xy, double size_z, double res,
+                             double cloud_res, int nthreads) {
+  TablesBatch* tb = new TablesBatch();
+  tb->worlds.assign(S, nullptr);
+  tb->starts.resize(S);
+  tb->goals.resize(S);
+  std::vector<std::vector<int>> lens(S);
+  std::vector<std::vector<double>> paths(S);
+  if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+  std::atomic<int> next(0);
+  auto worker = [&]() {
+    while (true) {
+      int sidx = next.fetch_add(1);
+      if (sidx >= S) break;
+      const uint64_t seed = base_seed + (uint64_t)sidx;
+      for (int attempt = 0; attempt < 64; attempt++) {
+        const uint64_t sd = seed * 1000 + attempt;
+        double s3[3], g3[3];
+        {
+          GridMap gm;
+          gm.init(size_xy, size_xy, size_z, 1.0);
+          Rng rng(sd);
+          World::sampleStartGoalXY(gm, rng, 3.0, 8.0, s3, g3);
+        }
+        World* w = new World();
+        std::vector<std::array<double, 2>> ko = {{s3[0], s3[1]}, {g3[0], g3[1]}};
+        w->build(0, sd, size_xy, size_z, res, cloud_res, ko, 1);
+        double start[10] = {s3[0], s3[1], s3[2], 0, 0, 0, 0, 0, 0, 0}, goal[10] = {g3[0], g3[1], g3[2], 0, 0, 0, 0, 0, 0, 0};
+        Rng ra(seed * 7919 + 2 * attempt), rb(seed * 7919 + 2 * attempt + 1);
+        bool ok = w->sampleArm(ra, goal) && w->sampleArm(rb, start);
+        std::vector<double> pth;
+        std::vector<int> ln;
+        if (ok) ok = w->initPaths(start, goal, n_cand, seed * 104729 + attempt, pth, ln) == n_cand;
+        if (!ok) { delete w; continue; }
+        tb->worlds[sidx] = w;
+        for (int q = 0; q < 10; q++) { tb->starts[sidx][q] = start[q]; tb->goals[sidx][q] = goal[q]; }
+        lens[sidx] = ln;
+        paths[sidx] = pth;
+        break;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+  for (int sidx = 0; sidx < S; sidx++) {
+    if (!tb->worlds[sidx]) continue;  // failed scenario: contributes nothing
+    for (int l : lens[sidx]) { tb->lens.push_back(l); tb->scen.push_back(sidx); }
+    tb->paths.insert(tb->paths.end(), paths[sidx].begin(), paths[sidx].end());
+  }
+  return tb;
+}
+void wl_tables_batch_destroy(void* h) {
+  TablesBatch* tb = (TablesBatch*)h;
+  for (World* w : tb->worlds) delete w;
+  delete tb;
+}
+int wl_tables_batch_ntraj(void* h) { return (int)((TablesBatch*)h)->lens.size(); }
+long long wl_tables_batch_nstates(void* h) { return (long long)((TablesBatch*)h)->paths.size() / 10; }
+void wl_tables_batch_get(void* h, int* lens, int* scen, double* paths) {
+  TablesBatch* tb = (TablesBatch*)h;
+  std::memcpy(lens, tb->lens.data(), tb->lens.size() * sizeof(int));
+  std::memcpy(scen, tb->scen.data(), tb->scen.size() * sizeof(int));
+  std::memcpy(paths, tb->paths.data(), tb->paths.size() * sizeof(double));
+}
+void* wl_tables_batch_world(void* h, int sidx) { return ((TablesBatch*)h)->worlds[sidx]; }
 
 }  // extern "C"
