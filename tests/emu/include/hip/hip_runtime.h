@@ -34,6 +34,8 @@
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static
+#define __constant__
+#define HIP_SYMBOL(x) (&(x))
 #define __restrict__ __restrict
 
 struct dim3 {
@@ -197,8 +199,33 @@ inline int __all(int pred) {
   unsigned long long full = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1);
   return (__ballot(pred) & full) == full;
 }
-inline int __builtin_amdgcn_readfirstlane(int v) { return hip_emu::exchange(v, hip_emu::S().cur & ~63); }
+// The kernels apply readfirstlane only to values that are already wave-uniform (to move them to scalar registers), also
+// under divergent control flow where a lane-exchange would not be collective: identity is the faithful emulation.
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hip_emu::exchange(v, (hip_emu::S().cur & ~63) + lane); }
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  const int me = hip_emu::S().cur, l = me & 15, base = me & ~15;
+  int from;
+  switch (ctrl) {
+    case 0xB1: from = base + (l ^ 1); break;                     // quad_perm [1,0,3,2]
+    case 0x4E: from = base + (l ^ 2); break;                     // quad_perm [2,3,0,1]
+    case 0x141: from = base + ((l & 8) | (7 - (l & 7))); break;  // row_half_mirror
+    case 0x140: from = base + (15 - l); break;                   // row_mirror
+    default: fprintf(stderr, "[hip_emu] unsupported dpp ctrl 0x%x\n", ctrl); abort();
+  }
+  return hip_emu::exchange(src, from);
+}
+inline void __builtin_amdgcn_wave_barrier() { hip_emu::barrier(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+inline unsigned long long __builtin_amdgcn_s_memtime() { return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count(); }
+inline int __double2loint(double v) { long long b; memcpy(&b, &v, 8); return (int)(b & 0xffffffffLL); }
+inline int __double2hiint(double v) { long long b; memcpy(&b, &v, 8); return (int)((b >> 32) & 0xffffffffLL); }
+inline double __hiloint2double(int hi, int lo) {
+  unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+  double v; memcpy(&v, &b, 8); return v;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline void __threadfence() {}
@@ -228,6 +255,10 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipMemcpyToSymbolAsync(void* sym, const void* src, size_t n, size_t off, hipMemcpyKind, hipStream_t) {
+  memcpy((char*)sym + off, src, n);
+  return 0;
+}
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

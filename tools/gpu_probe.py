@@ -8,7 +8,7 @@ from oracle import oracle as orc
 
 EMU = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "emu", "libtopay_emu.so")
 t0 = time.time()
-gpu = api.MomaTrajOptBatch(device=0)
+gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get('TOPAY_LIB'))
 emu = api.MomaTrajOptBatch(lib_path=EMU)
 print("ctx created", time.time() - t0, flush=True)
 
@@ -55,7 +55,7 @@ for bb in range(2):
           "x identical", bool((gpu.get_x(bb) == emu.get_x(bb)).all()), flush=True)
 
 # 4. batch solves: timing + stats vs oracle
-for S in (32, 256):
+for S in ((32, 256) if not os.environ.get('PROBE_QUICK') else ()):
     w2, lens2, paths2, scen2 = wl.cuboids_batch(S, 8)
     gpu.set_map(w2.origin, w2.res, w2.dims, w2.min_b, w2.max_b, w2.esdf2d, w2.esdf3d)
     gpu.set_init_traj(lens2, paths2)

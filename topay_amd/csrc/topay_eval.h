@@ -26,23 +26,58 @@
 #define HIP_DYN_SHARED_DECL extern __shared__ double topay_lds[];
 #endif
 
+// Optimizer/robot parameters live in constant memory: every access is a scalar load the compiler can re-issue at
+// the point of use instead of keeping hundreds of SGPRs of kernel arguments alive across the whole solve.
+__constant__ DevParams g_P;
+
 namespace topay {
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers (collectives: call only from wave-uniform control flow)
 // ---------------------------------------------------------------------------------------------
+// One fixed summation tree for every wave reduction: xor-butterfly with offsets 1,2,4,8 inside each 16-lane row
+// (DPP quad_perm / row_half_mirror / row_mirror; additions commute, so all lanes of a row end up with identical
+// bits), then (r0+r1)+(r2+r3) over the four rows via readlane.  Every lane receives the same bits, which keeps
+// wave-uniform control flow uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]   : lane ^ 1
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]   : lane ^ 2
+  v += dpp_f64<0x141>(v);  // row_half_mirror       : quad q <-> quad q^1
+  v += dpp_f64<0x140>(v);  // row_mirror            : half h <-> half h^1
+  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double o = __shfl_xor(v, off);
-    v = o > v ? o : v;
-  }
-  return v;
+  double o;
+  o = dpp_f64<0xB1>(v); v = o > v ? o : v;
+  o = dpp_f64<0x4E>(v); v = o > v ? o : v;
+  o = dpp_f64<0x141>(v); v = o > v ? o : v;
+  o = dpp_f64<0x140>(v); v = o > v ? o : v;
+  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+  const double a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+// LDS hand-off between lanes of the one wave of this workgroup: LDS operations of a wave complete in issue
+// order, so only compiler reordering has to be prevented (no s_barrier, no vmcnt drain).
+__device__ __forceinline__ void lds_sync() {
+#ifdef TOPAY_FULL_SYNC
+  __syncthreads();
+  return;
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 // inclusive prefix sum over lanes
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
@@ -89,26 +124,52 @@ __device__ __forceinline__ double dQdVq(double vq, double max_q) {
   double e1 = expC2(vq) + 1.0;
   return 2.0 * max_q * dTdTau(vq) / (e1 * e1);
 }
-// smoothL1Penalty, only meaningful for x > 0 — moma_traj_opt.h:810-830
+// smoothL1Penalty, only meaningful for x > 0 — moma_traj_opt.h:810-830 (constants precomputed in DevParams)
 __device__ __forceinline__ void smoothL1(double x, double mu, double& f, double& df) {
-  const double half = 0.5 * mu;
-  const double f3c = 1.0 / (mu * mu);
-  const double f4c = -0.5 * f3c / mu;
-  const double d2c = 3.0 * f3c;
-  const double d3c = 4.0 * f4c;
+  const DevParams& P = g_P;
   if (x < mu) {
-    f = (f4c * x + f3c) * x * x * x;
-    df = (d3c * x + d2c) * x * x;
+    f = (P.sl_f4c * x + P.sl_f3c) * x * x * x;
+    df = (P.sl_d3c * x + P.sl_d2c) * x * x;
   } else {
-    f = x - half;
+    f = x - P.sl_half;
     df = 1.0;
   }
 }
+// 1/K as a constant factor: the reference divides by int_K in every penalty term (e.g. moma_traj_opt.cpp:1315); a
+// multiplication by the rounded reciprocal differs by at most one ulp and saves an IEEE division per term.
+#define TOPAY_INV_K (1.0 / TOPAY_K)
 
 // ---------------------------------------------------------------------------------------------
 // ESDF interpolation — grid_map.h:364-441 (2-D), 443-509 (3-D); out of map => d = 0, grad = 0
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// Wave-uniform copy of a map descriptor, forced into scalar registers.
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ DevMap load_map(const TOPAY_GLB DevMap* mp) {
+  DevMap m;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    m.origin[a] = uniform_f64(mp->origin[a]);
+    m.min_b[a] = uniform_f64(mp->min_b[a]);
+    m.max_b[a] = uniform_f64(mp->max_b[a]);
+    m.dims[a] = __builtin_amdgcn_readfirstlane(mp->dims[a]);
+  }
+  m.res = uniform_f64(mp->res);
+  m.res_inv = uniform_f64(mp->res_inv);
+  m.pad = 0;
+  {
+    const unsigned long long p2 = (unsigned long long)mp->esdf2d, p3 = (unsigned long long)mp->esdf3d;
+    const unsigned lo2 = __builtin_amdgcn_readfirstlane((int)(p2 & 0xffffffffu)), hi2 = __builtin_amdgcn_readfirstlane((int)(p2 >> 32));
+    const unsigned lo3 = __builtin_amdgcn_readfirstlane((int)(p3 & 0xffffffffu)), hi3 = __builtin_amdgcn_readfirstlane((int)(p3 >> 32));
+    m.esdf2d = (glb_cdp)(((unsigned long long)hi2 << 32) | lo2);
+    m.esdf3d = (glb_cdp)(((unsigned long long)hi3 << 32) | lo3);
+  }
+  return m;
+}
 
 __device__ __forceinline__ void esdf2d_query(const DevMap& M, double px, double py, double& dist, double& gx, double& gy) {
   bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4);
@@ -122,7 +183,7 @@ __device__ __forceinline__ void esdf2d_query(const DevMap& M, double px, double 
     const int ny = M.dims[1];
     int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
     int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
-    const double* e = M.esdf2d;
+    glb_cdp e = M.esdf2d;
     double v00 = e[(size_t)x0 * ny + y0], v01 = e[(size_t)x0 * ny + y1];
     double v10 = e[(size_t)x1 * ny + y0], v11 = e[(size_t)x1 * ny + y1];
     double v0 = v00 * (1 - dx) + v10 * dx;
@@ -152,24 +213,25 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
     int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
     int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
     int z0 = clampi(iz, nz - 1), z1 = clampi(iz + 1, nz - 1);
-    const double* e = M.esdf3d;
+    glb_cdp e = M.esdf3d;
     size_t b00 = ((size_t)x0 * ny + y0) * nz, b01 = ((size_t)x0 * ny + y1) * nz;
     size_t b10 = ((size_t)x1 * ny + y0) * nz, b11 = ((size_t)x1 * ny + y1) * nz;
     double v000 = e[b00 + z0], v001 = e[b00 + z1], v010 = e[b01 + z0], v011 = e[b01 + z1];
     double v100 = e[b10 + z0], v101 = e[b10 + z1], v110 = e[b11 + z0], v111 = e[b11 + z1];
-    double v00 = v000 * (1 - dx) + v100 * dx;
-    double v01 = v001 * (1 - dx) + v101 * dx;
-    double v10 = v010 * (1 - dx) + v110 * dx;
-    double v11 = v011 * (1 - dx) + v111 * dx;
-    double v0 = v00 * (1 - dy) + v10 * dy;
-    double v1 = v01 * (1 - dy) + v11 * dy;
-    dist = v0 * (1.0 - dz) + v1 * dz;
+    const double ex = 1 - dx, ey = 1 - dy, ez = 1.0 - dz;
+    double v00 = fma(v100, dx, v000 * ex);
+    double v01 = fma(v101, dx, v001 * ex);
+    double v10 = fma(v110, dx, v010 * ex);
+    double v11 = fma(v111, dx, v011 * ex);
+    double v0 = fma(v10, dy, v00 * ey);
+    double v1 = fma(v11, dy, v01 * ey);
+    dist = fma(v1, dz, v0 * ez);
     gz = (v1 - v0) * ri;
-    gy = ((v10 - v00) * (1.0 - dz) + (v11 - v01) * dz) * ri;
-    double g0 = (1.0 - dz) * (1 - dy) * (v100 - v000);
-    g0 += (1.0 - dz) * dy * (v110 - v010);
-    g0 += dz * (1 - dy) * (v101 - v001);
-    g0 += dz * dy * (v111 - v011);
+    gy = fma(v11 - v01, dz, (v10 - v00) * ez) * ri;
+    double g0 = ez * ey * (v100 - v000);
+    g0 = fma(ez * dy, v110 - v010, g0);
+    g0 = fma(dz * ey, v101 - v001, g0);
+    g0 = fma(dz * dy, v111 - v011, g0);
     gx = g0 * ri;
   }
 }
@@ -180,54 +242,83 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
 struct EvalCtx {
   int lane, N, rows, n;
   // LDS
-  double* cL;    // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
-  double* Tp;    // [5][N]     T, T^2..T^5
-  double* hp;    // [54]       head PVA (27) | tail PVA (27), 9x3 col-major
-  double* gdT;   // [N]        penalty dJ/dT accumulator
-  double* pcs;   // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
-  double* X;     // union region: band+rdiag+adjoint (23*rows) | sample buffers (26N + 512)
+  lds_dp cL;     // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
+  lds_dp Tp;     // [5][N]     T, T^2..T^5
+  lds_dp hp;     // [54]       head PVA (27) | tail PVA (27), 9x3 col-major
+  lds_dp gdT;    // [N]        penalty dJ/dT accumulator
+  lds_dp pcs;    // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
+  lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
+  lds_dp X;      // union region: band+rdiag+adjoint (23*rows) | sample buffers (26N + 1024)
   // global
-  const double* x;
-  double* g;
-  double* lu;         // [14*rows] stash
-  const double* init_xy;
+  glb_cdp x;
+  glb_dp g;
+  glb_dp lu;          // [14*rows] stash
+  glb_cdp init_xy;
   double sx, sy, ex, ey;           // start xy, goal xy
   double lam0, lam1, rho0, rho1;   // ALM state
   double fxe0, fxe1;               // final_xy_error of this evaluation (stage 2)
+  // diagnostic build only (TOPAY_STAMPS): per-phase shader-clock accumulators, [16] per trajectory
+  TOPAY_GLB long long* stamps;
+  long long t_last;
 };
 
 __host__ __device__ __forceinline__ int lds_doubles(int Nmax) {
   const int rows = 6 * Nmax;
   int xr = 23 * rows;
-  int sr = 26 * Nmax + 512;
-  return 9 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + (xr > sr ? xr : sr);
+  int sr = 26 * Nmax + 1024;
+  return 18 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + (xr > sr ? xr : sr);
 }
-__device__ __forceinline__ void carve(EvalCtx& C, double* base, int Nmax) {
+__device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
   const int rows = 6 * Nmax;
   C.cL = base;
   C.Tp = C.cL + 9 * rows;
   C.hp = C.Tp + 5 * Nmax;
   C.gdT = C.hp + 54;
   C.pcs = C.gdT + Nmax;
-  C.X = C.pcs + 4 * (Nmax + 1);
+  C.gC = C.pcs + 4 * (Nmax + 1);
+  C.X = C.gC + 9 * rows;
 }
 
 #define BAND(i, j) band[((i) - (j) + 6) * rows + (j)]
 
+// Phase stamps for the diagnostic build (-DTOPAY_STAMPS): never compiled into the product library.
+#ifdef TOPAY_STAMPS
+#define STAMP(C, k)                                                    \
+  do {                                                                 \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();    \
+    if ((C).stamps && (C).lane == 0) (C).stamps[k] += now_ - (C).t_last; \
+    (C).t_last = (long long)__builtin_amdgcn_s_memtime();              \
+  } while (0)
+#else
+#define STAMP(C, k) do { } while (0)
+#endif
+// sub-interval stamp that does not reset the phase clock
+#ifdef TOPAY_STAMPS
+#define SUBSTAMP_BEGIN(C) const long long sub_t0_ = (long long)__builtin_amdgcn_s_memtime()
+#define SUBSTAMP_END(C, k)                                                                                   \
+  do {                                                                                                       \
+    if ((C).stamps && (C).lane == 0) (C).stamps[k] += (long long)__builtin_amdgcn_s_memtime() - sub_t0_;      \
+  } while (0)
+#else
+#define SUBSTAMP_BEGIN(C) do { } while (0)
+#define SUBSTAMP_END(C, k) do { } while (0)
+#endif
+
 // MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
 // factors (+ reciprocal diagonal) stashed in C.lu.
-__device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
+__device__ __noinline__ void minco_generate(EvalCtx& C) {
+  const DevParams& P = g_P;
   const int lane = C.lane, N = C.N, rows = C.rows;
-  double* band = C.X;
-  double* rdiag = C.X + 13 * rows;
-  double* cL = C.cL;
-  const double* Tau = C.x;
-  const double* Theta = C.x + N;
-  const double* Arc = C.x + 2 * N - 1;
-  const double* Vq = C.x + 3 * N - 1;
+  lds_dp band = C.X;
+  lds_dp rdiag = C.X + 13 * rows;
+  lds_dp cL = C.cL;
+  glb_cdp Tau = C.x;
+  glb_cdp Theta = C.x + N;
+  glb_cdp Arc = C.x + 2 * N - 1;
+  glb_cdp Vq = C.x + 3 * N - 1;
 
   for (int t = lane; t < 13 * rows; t += 64) band[t] = 0.0;
-  for (int t = lane; t < 9 * rows; t += 64) cL[t] = 0.0;
+  for (int t = lane; t < 9 * rows; t += 64) { cL[t] = 0.0; C.gC[t] = 0.0; }
   if (lane < N) {
     double T1 = expC2(Tau[lane]);  // calTfromTau, moma_traj_opt.h:778-786
     double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
@@ -235,7 +326,7 @@ __device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
     C.Tp[3 * N + lane] = T4; C.Tp[4 * N + lane] = T5;
     C.gdT[lane] = 0.0;
   }
-  __syncthreads();
+  lds_sync();
   // band fill — minco.hpp:838-896
   if (lane == 0) {
     BAND(0, 0) = 1.0; BAND(1, 1) = 1.0; BAND(2, 2) = 2.0;
@@ -282,8 +373,9 @@ __device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
     else v = sigmoidC2(Vq[i * 7 + d - 2], P.joint_pos_limit_max[d - 2]);
     cL[d * rows + 6 * i + 5] = v;
   }
-  __syncthreads();
+  lds_sync();
 
+  STAMP(C, 0);  // fill
   // LU without pivoting — banded_system.hpp:66-91.  Lane (t,u): row i = k+t (t=1..6), column j = k+u
   // (u=0 stores the multiplier, u=1..6 the rank-1 update).  The zero-skip tests of the reference
   // are arithmetic no-ops (0/x = 0, a - 0*c = a).
@@ -298,26 +390,27 @@ __device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
         const double m = aik / akk;
         nv = (u == 0) ? m : (BAND(i, j) - m * BAND(k, j));
       }
-      __syncthreads();
+      lds_sync();
       if (act) BAND(i, j) = nv;
-      __syncthreads();
+      lds_sync();
     }
   }
   for (int t = lane; t < rows; t += 64) rdiag[t] = 1.0 / BAND(t, t);
-  __syncthreads();
+  lds_sync();
+  STAMP(C, 1);  // LU
   // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118
   {
     const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
     for (int j = 0; j < rows; j++) {
       const int i = j + t;
       if (lane < 54 && i < rows) cL[d * rows + i] -= BAND(i, j) * cL[d * rows + j];
-      __syncthreads();
+      lds_sync();
     }
     // rows stay unscaled during the sweep; b(j)/A(j,j) is formed on the fly and applied at the end
     for (int j = rows - 1; j >= 0; j--) {
       const int i = j - t;
       if (lane < 54 && i >= 0) cL[d * rows + i] -= BAND(i, j) * (cL[d * rows + j] * rdiag[j]);
-      __syncthreads();
+      lds_sync();
     }
   }
   for (int t = lane; t < 9 * rows; t += 64) {
@@ -326,7 +419,8 @@ __device__ __forceinline__ void minco_generate(EvalCtx& C, const DevParams& P) {
   }
   // stash LU + reciprocal diagonal for the adjoint solve
   for (int t = lane; t < 14 * rows; t += 64) C.lu[t] = C.X[t];
-  __syncthreads();
+  lds_sync();
+  STAMP(C, 2);  // substitutions + stash
 }
 
 // polynomial basis of local time s: b0 = s^k, b1, b2, b3 derivatives — moma_traj_opt.cpp:1263-1270
@@ -341,31 +435,31 @@ __device__ __forceinline__ void make_basis(double s1, Basis& B) {
   B.b3[0] = 0.0; B.b3[1] = 0.0; B.b3[2] = 0.0; B.b3[3] = 6.0; B.b3[4] = 24.0 * s1; B.b3[5] = 60.0 * s2;
 }
 // value and derivatives of dimension d of piece i at the basis point (reads 6 coefficients from LDS)
-__device__ __forceinline__ void poly4(const double* cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
+__device__ __forceinline__ void poly4(lds_cdp cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
                                       double& p2, double& p3) {
-  const double* c = cL + d * rows + 6 * i;
+  lds_cdp c = cL + d * rows + 6 * i;
   const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-  p0 = c0 * B.b0[0] + c1 * B.b0[1] + c2 * B.b0[2] + c3 * B.b0[3] + c4 * B.b0[4] + c5 * B.b0[5];
-  p1 = c1 * B.b1[1] + c2 * B.b1[2] + c3 * B.b1[3] + c4 * B.b1[4] + c5 * B.b1[5];
-  p2 = c2 * B.b2[2] + c3 * B.b2[3] + c4 * B.b2[4] + c5 * B.b2[5];
-  p3 = c3 * B.b3[3] + c4 * B.b3[4] + c5 * B.b3[5];
+  p0 = fma(c5, B.b0[5], fma(c4, B.b0[4], fma(c3, B.b0[3], fma(c2, B.b0[2], fma(c1, B.b0[1], c0)))));
+  p1 = fma(c5, B.b1[5], fma(c4, B.b1[4], fma(c3, B.b1[3], fma(c2, B.b1[2], c1))));
+  p2 = fma(c5, B.b2[5], fma(c4, B.b2[4], fma(c3, B.b2[3], c2 * B.b2[2])));
+  p3 = fma(c5, B.b3[5], fma(c4, B.b3[4], c3 * B.b3[3]));
 }
-__device__ __forceinline__ void poly3(const double* cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
+__device__ __forceinline__ void poly3(lds_cdp cL, int rows, int i, int d, const Basis& B, double& p0, double& p1,
                                       double& p2) {
-  const double* c = cL + d * rows + 6 * i;
+  lds_cdp c = cL + d * rows + 6 * i;
   const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-  p0 = c0 * B.b0[0] + c1 * B.b0[1] + c2 * B.b0[2] + c3 * B.b0[3] + c4 * B.b0[4] + c5 * B.b0[5];
-  p1 = c1 * B.b1[1] + c2 * B.b1[2] + c3 * B.b1[3] + c4 * B.b1[4] + c5 * B.b1[5];
-  p2 = c2 * B.b2[2] + c3 * B.b2[3] + c4 * B.b2[4] + c5 * B.b2[5];
+  p0 = fma(c5, B.b0[5], fma(c4, B.b0[4], fma(c3, B.b0[3], fma(c2, B.b0[2], fma(c1, B.b0[1], c0)))));
+  p1 = fma(c5, B.b1[5], fma(c4, B.b1[4], fma(c3, B.b1[3], fma(c2, B.b1[2], c1))));
+  p2 = fma(c5, B.b2[5], fma(c4, B.b2[4], fma(c3, B.b2[3], c2 * B.b2[2])));
 }
 
 // integrand of the Simpson XY integral at local time s of piece i: sdot*(cos th, sin th)
-__device__ __forceinline__ void xy_integrand(const double* cL, int rows, int i, double s1, double& fx, double& fy) {
+__device__ __forceinline__ void xy_integrand(lds_cdp cL, int rows, int i, double s1, double& fx, double& fy) {
   const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
-  const double* ct = cL + 0 * rows + 6 * i;
-  const double* cs = cL + 1 * rows + 6 * i;
-  const double th = ct[0] + ct[1] * s1 + ct[2] * s2 + ct[3] * s3 + ct[4] * s4 + ct[5] * s5;
-  const double sd = cs[1] + cs[2] * (2.0 * s1) + cs[3] * (3.0 * s2) + cs[4] * (4.0 * s3) + cs[5] * (5.0 * s4);
+  lds_cdp ct = cL + 0 * rows + 6 * i;
+  lds_cdp cs = cL + 1 * rows + 6 * i;
+  const double th = fma(ct[5], s5, fma(ct[4], s4, fma(ct[3], s3, fma(ct[2], s2, fma(ct[1], s1, ct[0])))));
+  const double sd = fma(cs[5], 5.0 * s4, fma(cs[4], 4.0 * s3, fma(cs[3], 3.0 * s2, fma(cs[2], 2.0 * s1, cs[1]))));
   double sn, cn;
   det_sincos(th, &sn, &cn);
   fx = sd * cn;
@@ -389,27 +483,43 @@ __device__ __forceinline__ void joint_rotate(double* R, int i, double c_, double
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const double r0 = R[a * 3 + 0], r1 = R[a * 3 + 1];
-      R[a * 3 + 0] = r0 * c_ + r1 * s_;
-      R[a * 3 + 1] = -r0 * s_ + r1 * c_;
+      R[a * 3 + 0] = fma(r0, c_, r1 * s_);
+      R[a * 3 + 1] = fma(r1, c_, -(r0 * s_));
     }
   } else {  // R <- R * Ry(q): mixes columns 0,2
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const double r0 = R[a * 3 + 0], r2 = R[a * 3 + 2];
-      R[a * 3 + 0] = r0 * c_ - r2 * s_;
-      R[a * 3 + 2] = r0 * s_ + r2 * c_;
+      R[a * 3 + 0] = fma(r0, c_, -(r2 * s_));
+      R[a * 3 + 2] = fma(r0, s_, r2 * c_);
     }
   }
 }
 
-__device__ __forceinline__ void manipulator_block(const DevParams& P, const DevMap& M, const double* pos, double omg,
-                                                  double step, double sth, double cth, double* moma_grad, double& cost,
-                                                  double& gdTk) {
+struct ManiIn {
+  double pos[10];
+  double omg, step, sth, cth;
+};
+struct ManiOut {
+  double g[10];
+  double cost, gdT;
+};
+__device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, const ManiIn in) {
+  const DevParams& P = g_P;
+  const DevMap M = load_map(mp);
+  const double* pos = in.pos;
+  const double omg = in.omg, step = in.step, sth = in.sth, cth = in.cth;
+  ManiOut out;
+  double* moma_grad = out.g;
+  double cost, gdTk;
   const double mu = P.relu_mu;
   const double w = omg * step;
   double sq[7], cq[7];
 #pragma unroll
-  for (int i = 0; i < 7; i++) det_sincos(pos[3 + i], &sq[i], &cq[i]);
+  for (int i = 0; i < 7; i++) {
+    det_sincos(pos[3 + i], &sq[i], &cq[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   double A[9];
   {
     const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
@@ -422,8 +532,9 @@ __device__ __forceinline__ void manipulator_block(const DevParams& P, const DevM
   const double p0x = pos[0] + (cth * P.relT[0] - sth * P.relT[1]);
   const double p0y = pos[1] + (sth * P.relT[0] + cth * P.relT[1]);
   const double p0z = P.chassis_height + P.relT[2];
-  double Lx[TOPAY_NSPH], Ly[TOPAY_NSPH], Lz[TOPAY_NSPH];  // arm-local sphere centres rho_k
+  // walk 1: world sphere centres (the arm-local rho_k are not kept; the torque walks below regenerate them)
   // spheres per link: link0:{0,1} 1:{2} 2:{3,4} 3:{5} 4:{6,7} 5:{8} 6:{9,10} 7:{11}
+  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
   {
     double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
     double q0 = 0.0, q1 = 0.0, q2 = 0.0;
@@ -433,101 +544,111 @@ __device__ __forceinline__ void manipulator_block(const DevParams& P, const DevM
       const int cnt = (i % 2 == 0) ? 2 : 1;
 #pragma unroll
       for (int c = 0; c < cnt; c++) {
-        Lx[sidx] = q0 + R[2] * P.sph_off[sidx];
-        Ly[sidx] = q1 + R[5] * P.sph_off[sidx];
-        Lz[sidx] = q2 + R[8] * P.sph_off[sidx];
+        const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
+        Px[sidx] = p0x + fma(A[2], lz, fma(A[1], ly, A[0] * lx));
+        Py[sidx] = p0y + fma(A[5], lz, fma(A[4], ly, A[3] * lx));
+        Pz[sidx] = p0z + fma(A[8], lz, fma(A[7], ly, A[6] * lx));
         sidx++;
       }
-      q0 += R[2] * P.colli_length[i];
-      q1 += R[5] * P.colli_length[i];
-      q2 += R[8] * P.colli_length[i];
+      q0 = fma(R[2], P.colli_length[i], q0);
+      q1 = fma(R[5], P.colli_length[i], q1);
+      q2 = fma(R[8], P.colli_length[i], q2);
       if (i == 7) break;
       joint_rotate(R, i, cq[i], sq[i]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
-#pragma unroll
-  for (int k = 0; k < TOPAY_NSPH; k++) {
-    Px[k] = p0x + (A[0] * Lx[k] + A[1] * Ly[k] + A[2] * Lz[k]);
-    Py[k] = p0y + (A[3] * Lx[k] + A[4] * Ly[k] + A[5] * Lz[k]);
-    Pz[k] = p0z + (A[6] * Lx[k] + A[7] * Ly[k] + A[8] * Lz[k]);
-  }
   double Gx[TOPAY_NSPH], Gy[TOPAY_NSPH], Gz[TOPAY_NSPH];
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) { Gx[k] = 0.0; Gy[k] = 0.0; Gz[k] = 0.0; }
   cost = 0.0;
   gdTk = 0.0;
   const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
-  // environment collision
-#pragma unroll
-  for (int k = 0; k < TOPAY_NSPH; k++) {
-    double d, gx, gy, gz;
-    esdf3d_query(M, Px[k], Py[k], Pz[k], d, gx, gy, gz);
-    const double viola = P.sph_r[k] * 10.0 * 1.1 - d * 10.0;
-    Gx[k] = 0.0; Gy[k] = 0.0; Gz[k] = 0.0;
-    if (viola > 0) {
-      double pe, pd;
-      smoothL1(viola, mu, pe, pd);
-      const double sc = -w * wMC * pd;
-      Gx[k] = sc * gx * 10.0; Gy[k] = sc * gy * 10.0; Gz[k] = sc * gz * 10.0;
-      gdTk += omg * wMC * (pe / TOPAY_K);
-      cost += w * wMC * pe;
-    }
-  }
-  // chassis top — spheres with index > 2
-#pragma unroll
-  for (int k = 3; k < TOPAY_NSPH; k++) {
-    const double height = P.chassis_height + P.relT[2] + P.sph_r[k] - Pz[k];
-    if (height > 0) {
-      double pe, pd;
-      smoothL1(height, mu, pe, pd);
-      Gz[k] += -w * wSC * pd;
-      gdTk += omg * wSC * (pe / TOPAY_K);
-      cost += w * wSC * pe;
-    }
-  }
   // sphere pairs: collision_matrix == -1 <=> non-adjacent spheres (moma_param.h:128-143: at the zero pose
-  // only self and neighbouring spheres overlap)
+  // only self and neighbouring spheres overlap) — moma_traj_opt.cpp:1566-1611
 #pragma unroll
   for (int a = 0; a < TOPAY_NSPH; a++)
 #pragma unroll
     for (int b = a + 2; b < TOPAY_NSPH; b++) {
       const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
       const double rr = P.sph_r[a] + P.sph_r[b];
-      const double dist = rr * rr - (dx * dx + dy * dy + dz * dz);
+      const double dist = rr * rr - fma(dz, dz, fma(dy, dy, dx * dx));
       if (dist > 0) {
         double pe, pd;
         smoothL1(dist, mu, pe, pd);
         const double sc = -w * wSC * pd * 2.0;
-        Gx[a] += sc * dx; Gy[a] += sc * dy; Gz[a] += sc * dz;
-        Gx[b] -= sc * dx; Gy[b] -= sc * dy; Gz[b] -= sc * dz;
-        gdTk += omg * wSC * (pe / TOPAY_K);
+        Gx[a] = fma(sc, dx, Gx[a]); Gy[a] = fma(sc, dy, Gy[a]); Gz[a] = fma(sc, dz, Gz[a]);
+        Gx[b] = fma(-sc, dx, Gx[b]); Gy[b] = fma(-sc, dy, Gy[b]); Gz[b] = fma(-sc, dz, Gz[b]);
+        gdTk += omg * wSC * (pe * TOPAY_INV_K);
+        cost += w * wSC * pe;
+      }
+      if (b == TOPAY_NSPH - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520), one sphere at a
+  // time: the scheduling barrier keeps at most one sphere's eight gathers in flight (register budget)
+  double bFx = 0.0, bFy = 0.0, bMz = 0.0;  // base: x, y, yaw (everything rotates about the vertical axis through (x, y))
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    if (k >= 3) {
+      const double height = P.chassis_height + P.relT[2] + P.sph_r[k] - Pz[k];
+      if (height > 0) {
+        double pe, pd;
+        smoothL1(height, mu, pe, pd);
+        Gz[k] += -w * wSC * pd;
+        gdTk += omg * wSC * (pe * TOPAY_INV_K);
         cost += w * wSC * pe;
       }
     }
-  // base: x, y and yaw (everything rotates about the vertical axis through (x, y))
-  {
-    double Fx = 0, Fy = 0, Mz = 0;
-#pragma unroll
-    for (int k = 0; k < TOPAY_NSPH; k++) {
-      Fx += Gx[k]; Fy += Gy[k];
-      Mz += (Px[k] - pos[0]) * Gy[k] - (Py[k] - pos[1]) * Gx[k];
+    double d, gx, gy, gz;
+    esdf3d_query(M, Px[k], Py[k], Pz[k], d, gx, gy, gz);
+    const double viola = P.sph_r[k] * 10.0 * 1.1 - d * 10.0;
+    if (viola > 0) {
+      double pe, pd;
+      smoothL1(viola, mu, pe, pd);
+      const double sc = -w * wMC * pd;
+      Gx[k] += sc * gx * 10.0; Gy[k] += sc * gy * 10.0; Gz[k] += sc * gz * 10.0;
+      gdTk += omg * wMC * (pe * TOPAY_INV_K);
+      cost += w * wMC * pe;
     }
-    moma_grad[0] = Fx;
-    moma_grad[1] = Fy;
-    moma_grad[2] = Mz;
+    bFx += Gx[k];
+    bFy += Gy[k];
+    bMz = fma(Px[k] - pos[0], Gy[k], fma(-(Py[k] - pos[1]), Gx[k], bMz));
+    // g' = A^T g (arm-local frame), in place; world position no longer needed
+    const double tx = fma(A[6], Gz[k], fma(A[3], Gy[k], A[0] * Gx[k]));
+    const double ty = fma(A[7], Gz[k], fma(A[4], Gy[k], A[1] * Gx[k]));
+    const double tz = fma(A[8], Gz[k], fma(A[5], Gy[k], A[2] * Gx[k]));
+    Gx[k] = tx; Gy[k] = ty; Gz[k] = tz;
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // joints: g' = A^T g in the arm-local frame, then walk the chain again peeling off the links at or below
-  // each joint:  tau_i = u_i . (Mo_beyond - o_{i+1} x F_beyond)
+  moma_grad[0] = bFx;
+  moma_grad[1] = bFy;
+  moma_grad[2] = bMz;
+  // joints: tau_i = u_i . (Mo_beyond - o_{i+1} x F_beyond) with F, Mo = sums of g' and rho x g'.
+  // walk 2a accumulates the totals, walk 2b peels off the links at or below each joint.
   double Fx = 0, Fy = 0, Fz = 0, Mx = 0, My = 0, Mz = 0;
+  {
+    double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    int sidx = 0;
 #pragma unroll
-  for (int k = 0; k < TOPAY_NSPH; k++) {
-    const double gx = A[0] * Gx[k] + A[3] * Gy[k] + A[6] * Gz[k];
-    const double gy = A[1] * Gx[k] + A[4] * Gy[k] + A[7] * Gz[k];
-    const double gz = A[2] * Gx[k] + A[5] * Gy[k] + A[8] * Gz[k];
-    Gx[k] = gx; Gy[k] = gy; Gz[k] = gz;
-    Fx += gx; Fy += gy; Fz += gz;
-    Mx += Ly[k] * gz - Lz[k] * gy;
-    My += Lz[k] * gx - Lx[k] * gz;
-    Mz += Lx[k] * gy - Ly[k] * gx;
+    for (int i = 0; i < 8; i++) {
+      const int cnt = (i % 2 == 0) ? 2 : 1;
+#pragma unroll
+      for (int c = 0; c < cnt; c++) {
+        const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
+        Fx += Gx[sidx]; Fy += Gy[sidx]; Fz += Gz[sidx];
+        Mx = fma(ly, Gz[sidx], fma(-lz, Gy[sidx], Mx));
+        My = fma(lz, Gx[sidx], fma(-lx, Gz[sidx], My));
+        Mz = fma(lx, Gy[sidx], fma(-ly, Gx[sidx], Mz));
+        sidx++;
+      }
+      q0 = fma(R[2], P.colli_length[i], q0);
+      q1 = fma(R[5], P.colli_length[i], q1);
+      q2 = fma(R[8], P.colli_length[i], q2);
+      if (i == 7) break;
+      joint_rotate(R, i, cq[i], sq[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   {
     double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
@@ -538,23 +659,25 @@ __device__ __forceinline__ void manipulator_block(const DevParams& P, const DevM
       const int cnt = (i % 2 == 0) ? 2 : 1;
 #pragma unroll
       for (int c = 0; c < cnt; c++) {  // remove link i's spheres from the "beyond" sums
+        const double lx = fma(R[2], P.sph_off[sidx], o0), ly = fma(R[5], P.sph_off[sidx], o1), lz = fma(R[8], P.sph_off[sidx], o2);
         Fx -= Gx[sidx]; Fy -= Gy[sidx]; Fz -= Gz[sidx];
-        Mx -= Ly[sidx] * Gz[sidx] - Lz[sidx] * Gy[sidx];
-        My -= Lz[sidx] * Gx[sidx] - Lx[sidx] * Gz[sidx];
-        Mz -= Lx[sidx] * Gy[sidx] - Ly[sidx] * Gx[sidx];
+        Mx = fma(-ly, Gz[sidx], fma(lz, Gy[sidx], Mx));
+        My = fma(-lz, Gx[sidx], fma(lx, Gz[sidx], My));
+        Mz = fma(-lx, Gy[sidx], fma(ly, Gx[sidx], Mz));
         sidx++;
       }
-      o0 += R[2] * P.colli_length[i];
-      o1 += R[5] * P.colli_length[i];
-      o2 += R[8] * P.colli_length[i];
+      o0 = fma(R[2], P.colli_length[i], o0);
+      o1 = fma(R[5], P.colli_length[i], o1);
+      o2 = fma(R[8], P.colli_length[i], o2);
       // joint i turns frame i about its local z (even i) or y (odd i) axis through o_{i+1}
       const int ac = (i % 2 == 0) ? 2 : 1;
       const double ax = R[0 * 3 + ac], ay = R[1 * 3 + ac], az = R[2 * 3 + ac];
-      const double tx = Mx - (o1 * Fz - o2 * Fy);
-      const double ty = My - (o2 * Fx - o0 * Fz);
-      const double tz = Mz - (o0 * Fy - o1 * Fx);
-      moma_grad[3 + i] = ax * tx + ay * ty + az * tz;
+      const double tx = Mx - fma(o1, Fz, -(o2 * Fy));
+      const double ty = My - fma(o2, Fx, -(o0 * Fz));
+      const double tz = Mz - fma(o0, Fy, -(o1 * Fx));
+      moma_grad[3 + i] = fma(az, tz, fma(ay, ty, ax * tx));
       joint_rotate(R, i, cq[i], sq[i]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // joint position limits — moma_traj_opt.cpp:1616-1666 (symmetric joint_pos_limit_max, reference quirk)
@@ -566,7 +689,7 @@ __device__ __forceinline__ void manipulator_block(const DevParams& P, const DevM
       double pe, pd;
       smoothL1(v, mu, pe, pd);
       moma_grad[ji + 3] += w * wJP * pd;
-      gdTk += omg * wJP * (pe / TOPAY_K);
+      gdTk += omg * wJP * (pe * TOPAY_INV_K);
       cost += w * wJP * pe;
     }
     v = -P.joint_pos_limit_max[ji] - pos[ji + 3];
@@ -574,10 +697,13 @@ __device__ __forceinline__ void manipulator_block(const DevParams& P, const DevM
       double pe, pd;
       smoothL1(v, mu, pe, pd);
       moma_grad[ji + 3] -= w * wJP * pd;
-      gdTk += omg * wJP * (pe / TOPAY_K);
+      gdTk += omg * wJP * (pe * TOPAY_INV_K);
       cost += w * wJP * pe;
     }
   }
+  out.cost = cost;
+  out.gdT = gdTk;
+  return out;
 }
 
 // kinodynamic penalties shared by both stages — moma_traj_opt.cpp:1059-1115 / 1334-1462.
@@ -599,7 +725,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
       const double gt = real_alpha * (sgn * max_v * th2 + max_w * sd2);
       gth1 += w * wM * pd * sgn * max_v;
       gs1 += w * wM * pd * max_w;
-      gdT += omg * wM * (pd * gt * step + pe / TOPAY_K);
+      gdT += omg * wM * (pd * gt * step + pe * TOPAY_INV_K);
       cost += w * wM * pe;
     }
   }
@@ -612,7 +738,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
       const double gt = real_alpha * (sgn * max_v * th2 - max_w * sd2);
       gth1 += w * wM * pd * sgn * max_v;
       gs1 -= w * wM * pd * max_w;
-      gdT += omg * wM * (pd * gt * step + pe / TOPAY_K);
+      gdT += omg * wM * (pd * gt * step + pe * TOPAY_INV_K);
       cost += w * wM * pe;
     }
   }
@@ -623,7 +749,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
     smoothL1(vAcc, mu, pe, pd);
     const double gt = 2.0 * real_alpha * sd2 * sd3;
     gs2 += w * wA * pd * 2.0 * sd2;
-    gdT += omg * wA * (pd * gt * step + pe / TOPAY_K);
+    gdT += omg * wA * (pd * gt * step + pe * TOPAY_INV_K);
     cost += w * wA * pe;
   }
   if (vAlp > 0) {
@@ -631,7 +757,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
     smoothL1(vAlp, mu, pe, pd);
     const double gt = 2.0 * real_alpha * th2 * th3;
     gth2 += w * wD * pd * 2.0 * th2;
-    gdT += omg * wD * (pd * gt * step + pe / TOPAY_K);
+    gdT += omg * wD * (pd * gt * step + pe * TOPAY_INV_K);
     cost += w * wD * pe;
   }
 }
@@ -656,10 +782,11 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 // RMAX = rows per lane (1: N <= 10, 2: N <= 21).  Returns f (wave-uniform); writes g[n].
 // ---------------------------------------------------------------------------------------------
 template <int STAGE, int RMAX>
-__device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P, const DevMap& M) {
+__device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp) {
+  const DevParams& P = g_P;
   const int lane = C.lane, N = C.N, rows = C.rows;
-  const double* cL = C.cL;
-  minco_generate(C, P);
+  lds_cdp cL = C.cL;
+  minco_generate(C);
 
   // ---- jerk energy & dJ/dT per piece — minco.hpp:923-942, 978-994 (lanes <-> pieces)
   double jerk_gdT = 0.0, jerk_e = 0.0;
@@ -678,23 +805,22 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
     jerk_gdT = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
   }
   const double jerk_cost = wave_sum(jerk_e);
+  STAMP(C, 3);  // jerk
 
   // ---- row-lane bookkeeping
   int rrow[RMAX], rpiece[RMAX], rk[RMAX];
   bool ract[RMAX];
-  double acc[RMAX][9];
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
     rrow[r] = lane + 64 * r;
     ract[r] = rrow[r] < rows;
     rpiece[r] = rrow[r] / 6;
     rk[r] = rrow[r] - 6 * rpiece[r];
-#pragma unroll
-    for (int d = 0; d < 9; d++) acc[r][d] = 0.0;
   }
+  lds_dp gC = C.gC;
 
-  double* gxy = C.X;                 // [13N][2] positional gradient of each even sample
-  double* pbuf = C.X + 26 * N;       // [8][64] pass buffer
+  lds_dp gxy = C.X;                  // [13N][2] positional gradient of each even sample
+  lds_dp pbuf = C.X + 26 * N;        // [16][64] pass buffer (also the per-lane stash around the manipulator block)
   const int NE = TOPAY_EP * N;       // even samples
   const int npass = (NE + 63) / 64;
   double cost_pen = 0.0;             // per-lane partial penalty cost
@@ -739,6 +865,7 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
     for (int v = 0; v < 12; v++) gB[v] = 0.0;
     double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
     bool jva = false;
+    SUBSTAMP_BEGIN(C);
     if (act) {
       Basis B;
       make_basis(j * half, B);
@@ -755,7 +882,10 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
         det_sincos(th0, &sth, &cth);
         // chassis collision — moma_traj_opt.cpp:1304-1332
         double d2, g2x, g2y;
-        esdf2d_query(M, posx, posy, d2, g2x, g2y);
+        {
+          const DevMap M = load_map(mp);
+          esdf2d_query(M, posx, posy, d2, g2x, g2y);
+        }
         const double viola = P.chassis_colli_radius * 1.05 - d2;
         if (viola > 0) {
           double pe, pd;
@@ -763,7 +893,7 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
           const double sc = -omg * step * P.s2_collision_weight * pd;
           gpx += sc * g2x;
           gpy += sc * g2y;
-          gdTs += omg * P.s2_collision_weight * (pe / TOPAY_K);
+          gdTs += omg * P.s2_collision_weight * (pe * TOPAY_INV_K);
           cst += omg * step * P.s2_collision_weight * pe;
         }
         // manipulator
@@ -783,35 +913,58 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
           if (vDq > 0) {
             double pe, pd;
             smoothL1(vDq, P.relu_mu, pe, pd);
-            gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe / TOPAY_K);
+            gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe * TOPAY_INV_K);
             cst += omg * step * P.s2_mani_vel_weight * pe;
             jva = true;
           }
           if (vD2q > 0) {
             double pe, pd;
             smoothL1(vD2q, P.relu_mu, pe, pd);
-            gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe / TOPAY_K);
+            gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe * TOPAY_INV_K);
             cst += omg * step * P.s2_mani_acc_weight * pe;
             jva = true;
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        double mg[10], mcost, mgdT;
-        manipulator_block(P, M, pos, omg, step, sth, cth, mg, mcost, mgdT);
-        cst += mcost;
-        gdTs += mgdT;
+        // park the per-sample context in this lane's LDS column while the manipulator block runs: it needs nearly
+        // the whole register budget for the 12 sphere centres and their gradients
+        pbuf[0 * 64 + lane] = th1;
+#pragma unroll
+        for (int q = 0; q < 7; q++) pbuf[(1 + q) * 64 + lane] = q1[q];
+#pragma unroll
+        for (int v = 1; v < 5; v++) pbuf[(7 + v) * 64 + lane] = gB[v];
+        pbuf[12 * 64 + lane] = gdTs;
+        pbuf[13 * 64 + lane] = cst;
+        ManiIn min_;
+#pragma unroll
+        for (int q = 0; q < 10; q++) min_.pos[q] = pos[q];
+        min_.omg = omg; min_.step = step; min_.sth = sth; min_.cth = cth;
+#ifdef TOPAY_STAMPS
+        const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        const ManiOut mo_ = manipulator_block(mp, min_);
+#ifdef TOPAY_STAMPS
+        if (C.stamps && lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
+#endif
+        const double* mg = mo_.g;
+        cst = pbuf[13 * 64 + lane] + mo_.cost;
+        gdTs = pbuf[12 * 64 + lane] + mo_.gdT;
+#pragma unroll
+        for (int v = 1; v < 5; v++) gB[v] = pbuf[(7 + v) * 64 + lane];
         gpx += mg[0];
         gpy += mg[1];
         gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
-        gdTs += mg[2] * th1 * real_alpha;   // (1670)
+        gdTs += mg[2] * pbuf[0 * 64 + lane] * real_alpha;   // (1670)
 #pragma unroll
         for (int q = 0; q < 7; q++) {
           gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
-          qacc += mg[3 + q] * q1[q];
+          qacc += mg[3 + q] * pbuf[(1 + q) * 64 + lane];
         }
         gdTs += qacc * real_alpha;          // (1672)
       }
       cost_pen += cst;
     }
+    SUBSTAMP_END(C, 12);  // sample body of lane 0
     if (act) {
       gxy[2 * e] = gpx;
       gxy[2 * e + 1] = gpy;
@@ -820,49 +973,59 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
 #pragma unroll
     for (int v = 0; v < 5; v++) pbuf[v * 64 + lane] = gB[v];
     pbuf[5 * 64 + lane] = gdTs;
-    __syncthreads();
+    lds_sync();
 #pragma unroll
     for (int r = 0; r < RMAX; r++) {
       if (ract[r]) {
         const int pi = rpiece[r];
         const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
         const double hs = C.Tp[pi] / TOPAY_K / 2.0;
-        double gt = 0.0;
+        double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
         for (int ee = e_lo; ee < e_hi; ee++) {
           const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
           double b0, b1, b2;
           basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
-          acc[r][0] += b0 * pbuf[0 * 64 + l] + b1 * pbuf[1 * 64 + l] + b2 * pbuf[2 * 64 + l];
-          acc[r][1] += b1 * pbuf[3 * 64 + l] + b2 * pbuf[4 * 64 + l];
+          a0 += fma(b2, pbuf[2 * 64 + l], fma(b1, pbuf[1 * 64 + l], b0 * pbuf[0 * 64 + l]));
+          a1 += fma(b2, pbuf[4 * 64 + l], b1 * pbuf[3 * 64 + l]);
           gt += pbuf[5 * 64 + l];
         }
+        gC[0 * rows + rrow[r]] = a0;
+        gC[1 * rows + rrow[r]] = a1;
         if (rk[r] == 0) C.gdT[pi] += gt;
       }
     }
-    __syncthreads();
+    lds_sync();
     if (STAGE == 2) {
       // Round B: joint rows of order 0
 #pragma unroll
       for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = gB[5 + v];
-      __syncthreads();
+      lds_sync();
 #pragma unroll
       for (int r = 0; r < RMAX; r++) {
         if (ract[r]) {
           const int pi = rpiece[r];
           const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
           const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+          double aq[7];
+#pragma unroll
+          for (int q = 0; q < 7; q++) aq[q] = gC[(2 + q) * rows + rrow[r]];
           for (int ee = e_lo; ee < e_hi; ee++) {
             const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
             double b0, b1, b2;
             basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
 #pragma unroll
-            for (int q = 0; q < 7; q++) acc[r][2 + q] += b0 * pbuf[q * 64 + l];
+            for (int q = 0; q < 7; q++) aq[q] = fma(b0, pbuf[q * 64 + l], aq[q]);
           }
+#pragma unroll
+          for (int q = 0; q < 7; q++) gC[(2 + q) * rows + rrow[r]] = aq[q];
         }
       }
-      __syncthreads();
-      // Round C (rare): joint velocity / acceleration gradBeta rows 1 and 2 — moma_traj_opt.cpp:1689, 1703
-      if (__any(jva)) {
+      lds_sync();
+      // Round C (rare): joint velocity / acceleration gradBeta rows 1 and 2 — moma_traj_opt.cpp:1689, 1703.
+      // Few samples ever trigger these limits, so the flagged lanes are visited one at a time (wave-uniform loop
+      // over the ballot): the lane's 14 values are broadcast and every row lane of its piece adds its own entry.
+      // No two lanes touch the same accumulator, so the result does not depend on timing.
+      {
         double g1[7], g2[7];
 #pragma unroll
         for (int q = 0; q < 7; q++) { g1[q] = 0.0; g2[q] = 0.0; }
@@ -888,39 +1051,43 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
             }
           }
         }
+        unsigned long long todo = __ballot(act && jva);
+        while (todo) {
+          const int src = __ffsll(todo) - 1;
+          todo &= todo - 1;
+          const int se = pass * 64 + src;           // flat even-sample index of the flagged lane
+          const int spi = se / TOPAY_EP, smm = se - TOPAY_EP * spi;
+          double b1v[7], b2v[7];
 #pragma unroll
-        for (int half_r = 0; half_r < 2; half_r++) {
-#pragma unroll
-          for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = half_r == 0 ? g1[v] : g2[v];
-          __syncthreads();
+          for (int q = 0; q < 7; q++) { b1v[q] = readlane_f64(g1[q], src); b2v[q] = readlane_f64(g2[q], src); }
 #pragma unroll
           for (int r = 0; r < RMAX; r++) {
-            if (ract[r]) {
-              const int pi = rpiece[r];
-              const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-              const double hs = C.Tp[pi] / TOPAY_K / 2.0;
-              for (int ee = e_lo; ee < e_hi; ee++) {
-                const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-                double b0, b1, b2;
-                basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
-                const double bb = half_r == 0 ? b1 : b2;
+            if (ract[r] && rpiece[r] == spi) {
+              const double hs = C.Tp[spi] / TOPAY_K / 2.0;
+              double b0, b1, b2;
+              basis_k(rk[r], (2 * smm) * hs, b0, b1, b2);
 #pragma unroll
-                for (int q = 0; q < 7; q++) acc[r][2 + q] += bb * pbuf[q * 64 + l];
+              for (int q = 0; q < 7; q++) {
+                double a = gC[(2 + q) * rows + rrow[r]];
+                a = fma(b1, b1v[q], a);
+                a = fma(b2, b2v[q], a);
+                gC[(2 + q) * rows + rrow[r]] = a;
               }
             }
           }
-          __syncthreads();
         }
+        lds_sync();
       }
     }
   }
 
+  STAMP(C, 4);  // sweep 1
   // ---- per-piece terms between the sweeps
   double cost_piece = 0.0;
   double chain0x = 0.0, chain0y = 0.0;  // constant added to every chain entry (ALM term)
   if (STAGE == 1) {
     // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
-    __syncthreads();
+    lds_sync();
     if (lane < N) {
       const double ex = C.pcs[2 * N + 2 * (lane + 1)] - C.init_xy[2 * lane];
       const double ey = C.pcs[2 * N + 2 * (lane + 1) + 1] - C.init_xy[2 * lane + 1];
@@ -928,7 +1095,7 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
       C.pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
       C.pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
     }
-    __syncthreads();
+    lds_sync();
   } else {
     // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
     const double Tm = lane < N ? C.Tp[lane] : 0.0;
@@ -962,8 +1129,9 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
   double penalty_cost = wave_sum(cost_pen + cost_piece);
   // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
   const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
-  __syncthreads();
+  lds_sync();
 
+  STAMP(C, 5);  // between sweeps
   // =========================== sweep 2: backward, XY-gradient chain ===========================
   if (!bad) {
     double rcarryx = chain0x, rcarryy = chain0y;
@@ -1018,42 +1186,42 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
       }
       pbuf[0 * 64 + lane] = v0; pbuf[1 * 64 + lane] = v1; pbuf[2 * 64 + lane] = v2; pbuf[3 * 64 + lane] = v3;
       pbuf[4 * 64 + lane] = vT;
-      __syncthreads();
+      lds_sync();
 #pragma unroll
       for (int r = 0; r < RMAX; r++) {
         if (ract[r]) {
           const int pi = rpiece[r];
           const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
           const double hs = C.Tp[pi] / TOPAY_K / 2.0;
-          double gt = 0.0;
+          double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
           for (int ee = e_lo; ee < e_hi; ee++) {
             const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
             double b0, b1, b2, o0, o1, o2;
             basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
             basis_k(rk[r], (2 * mm + 1) * hs, o0, o1, o2);
-            acc[r][0] += b0 * pbuf[0 * 64 + l] + o0 * pbuf[2 * 64 + l];
-            acc[r][1] += b1 * pbuf[1 * 64 + l] + o1 * pbuf[3 * 64 + l];
+            a0 += fma(o0, pbuf[2 * 64 + l], b0 * pbuf[0 * 64 + l]);
+            a1 += fma(o1, pbuf[3 * 64 + l], b1 * pbuf[1 * 64 + l]);
             gt += pbuf[4 * 64 + l];
           }
+          gC[0 * rows + rrow[r]] = a0;
+          gC[1 * rows + rrow[r]] = a1;
           if (rk[r] == 0) C.gdT[pi] += gt;
         }
       }
-      __syncthreads();
+      lds_sync();
     }
   } else {
     penalty_cost = 1.0e+22;
-#pragma unroll
-    for (int r = 0; r < RMAX; r++)
-#pragma unroll
-      for (int d = 0; d < 9; d++) acc[r][d] = 0.0;
+    for (int t = lane; t < 9 * rows; t += 64) gC[t] = 0.0;
     if (lane < N) C.gdT[lane] = 0.0;
-    __syncthreads();
+    lds_sync();
   }
 
+  STAMP(C, 6);  // sweep 2
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
-  double* band = C.X;
-  double* rdiag = C.X + 13 * rows;
-  double* adj = C.X + 14 * rows;  // [9][rows]
+  lds_dp band = C.X;
+  lds_dp rdiag = C.X + 13 * rows;
+  lds_dp adj = C.X + 14 * rows;  // [9][rows]
   for (int t = lane; t < 14 * rows; t += 64) C.X[t] = C.lu[t];
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -1070,26 +1238,27 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
           else if (k == 4) jg = 144.0 * c3 * e * T2 + 384.0 * c4 * e * T3 + 720.0 * c5 * e * T4;
           else jg = 72.0 * c3 * e * T1 + 144.0 * c4 * e * T2 + 240.0 * c5 * e * T3;
         }
-        adj[d * rows + rrow[r]] = jg + acc[r][d];
+        adj[d * rows + rrow[r]] = jg + gC[d * rows + rrow[r]];
       }
     }
   }
-  __syncthreads();
+  lds_sync();
   {
     const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
     for (int j = 0; j < rows; j++) {  // b(j) /= A(j,j); b(i) -= A(j,i) b(j), i = j+1..j+6
       const int i = j + t;
       if (lane < 54 && i < rows) adj[d * rows + i] -= BAND(j, i) * (adj[d * rows + j] * rdiag[j]);
-      __syncthreads();
+      lds_sync();
     }
     for (int tt = lane; tt < 9 * rows; tt += 64) adj[tt] *= rdiag[tt % rows];
-    __syncthreads();
+    lds_sync();
     for (int j = rows - 1; j >= 0; j--) {  // b(i) -= A(j,i) b(j), i = j-6..j-1
       const int i = j - t;
       if (lane < 54 && i >= 0) adj[d * rows + i] -= BAND(j, i) * adj[d * rows + j];
-      __syncthreads();
+      lds_sync();
     }
   }
+  STAMP(C, 7);  // adjoint solve
   // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
   // each row lane forms its row's dot product, partial sums per piece go through rdiag[] (free now)
 #pragma unroll
@@ -1107,7 +1276,7 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
         const double T1 = C.Tp[pi], T2 = C.Tp[N + pi], T3 = C.Tp[2 * N + pi], T4 = C.Tp[3 * N + pi];
 #pragma unroll
         for (int d = 0; d < 9; d++) {
-          const double* c = cL + d * rows + 6 * pi;
+          lds_cdp c = cL + d * rows + 6 * pi;
           const double c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
           double b;
           if (br == 0) b = -(24.0 * c4 + 120.0 * T1 * c5);                    // -snap
@@ -1121,7 +1290,7 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
       rdiag[row] = part;
     }
   }
-  __syncthreads();
+  lds_sync();
   double gdT_tot = 0.0;
   if (lane < N) {
     const int i = lane;
@@ -1132,8 +1301,8 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
   }
   // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948
   const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
-  const double* Tau = C.x;
-  const double* Vq = C.x + 3 * N - 1;
+  glb_cdp Tau = C.x;
+  glb_cdp Vq = C.x + 3 * N - 1;
   double tsum = 0.0;
   if (lane < N) {
     C.g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
@@ -1148,7 +1317,8 @@ __device__ __forceinline__ double eval_cost_grad(EvalCtx& C, const DevParams& P,
   }
   if (lane == 0) C.g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
   const double time_cost = wT * wave_sum(tsum);
-  __syncthreads();
+  __syncthreads();  // g (global memory) becomes visible to the lanes that read it next
+  STAMP(C, 8);  // gradient assembly
   return jerk_cost + penalty_cost + time_cost;
 }
 

@@ -12,23 +12,28 @@
 
 #include "topay_solve.h"
 
+// minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane)
+#ifndef TOPAY_WAVES_PER_EU
+#define TOPAY_WAVES_PER_EU 2
+#endif
+
 using namespace topay;
 
 #ifndef TOPAY_CPU_EMU
 extern __shared__ double topay_lds[];
-#define TOPAY_LDS_PTR topay_lds
+#define TOPAY_LDS_PTR ((lds_dp)topay_lds)
 #else
-#define TOPAY_LDS_PTR ((double*)hip_emu::S().dyn_smem)
+#define TOPAY_LDS_PTR ((lds_dp)hip_emu::S().dyn_smem)
 #endif
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void k_init(DevParams P, DevBatch Bt, const double* paths, const long long* path_off, const int* path_len,
+__global__ void k_init(DevBatch Bt, const double* paths, const long long* path_off, const int* path_len,
                        const double* bvel, const double* bacc, double* scratch, int scratch_stride, int maxN, int stride_n) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bt.B) return;
-  init_one(P, paths + path_off[b] * 10, path_len[b], bvel + (size_t)b * 20, bacc + (size_t)b * 20,
+  init_one(g_P, paths + path_off[b] * 10, path_len[b], bvel + (size_t)b * 20, bacc + (size_t)b * 20,
            scratch + (size_t)b * scratch_stride, maxN, Bt.N + b, Bt.s1_past + b, Bt.head + (size_t)b * 27,
            Bt.tail + (size_t)b * 27, Bt.start_xy + 2 * b, Bt.goal_xy + 2 * b, Bt.init_xy + (size_t)b * 2 * maxN,
            Bt.x0 + (size_t)b * stride_n);
@@ -44,29 +49,36 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
     C.hp[t] = Bt.head[(size_t)b * 27 + t];
     C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
   }
-  C.lu = Bt.lu + (size_t)b * 14 * 6 * Bt.Nmax;
-  C.init_xy = Bt.init_xy + (size_t)b * 2 * init_stride_N;
+  C.lu = (glb_dp)(Bt.lu + (size_t)b * 14 * 6 * Bt.Nmax);
+  C.init_xy = (glb_cdp)(Bt.init_xy + (size_t)b * 2 * init_stride_N);
   C.sx = Bt.start_xy[2 * b]; C.sy = Bt.start_xy[2 * b + 1];
   C.ex = Bt.goal_xy[2 * b];  C.ey = Bt.goal_xy[2 * b + 1];
   C.fxe0 = 0.0; C.fxe1 = 0.0;
+  C.stamps = nullptr;
+  C.t_last = 0;
+#ifdef TOPAY_STAMPS
+  // diagnostic build: the trace buffer (topay_set_trace with cap >= 32) doubles as the stamp accumulator
+  if (Bt.trace && Bt.trace_cap >= 32) C.stamps = (TOPAY_GLB long long*)(Bt.trace + (size_t)b * Bt.trace_cap) + 8;
+  C.t_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
 }
 
 // test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
 template <int RMAX>
-__device__ __forceinline__ void eval_body(const DevParams& P, const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds,
+__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds,
                                           int init_stride_N, int repeats) {
   const int b = Bt.order[blockIdx.x];
   EvalCtx C;
   load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
-  const DevMap M = maps[Bt.map_id[b]];
-  C.x = Bt.x + (size_t)b * Bt.nmax;
-  C.g = Bt.work + (size_t)b * 4 * Bt.nmax;
+  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
+  C.x = (glb_cdp)(Bt.x + (size_t)b * Bt.nmax);
+  C.g = (glb_dp)(Bt.work + (size_t)b * 4 * Bt.nmax);
   C.lam0 = Bt.alm[4 * b]; C.lam1 = Bt.alm[4 * b + 1]; C.rho0 = Bt.alm[4 * b + 2]; C.rho1 = Bt.alm[4 * b + 3];
   __syncthreads();
   double f = 0.0;
   for (int r = 0; r < repeats; r++) {
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, P, M);
-    else f = eval_cost_grad<2, RMAX>(C, P, M);
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp);
+    else f = eval_cost_grad<2, RMAX>(C, mp);
   }
   if (C.lane == 0) {
     Bt.fout[b] = f;
@@ -76,26 +88,26 @@ __device__ __forceinline__ void eval_body(const DevParams& P, const DevBatch& Bt
 }
 
 template <int RMAX>
-__device__ __forceinline__ void solve_body(const DevParams& P, const DevBatch& Bt, const DevMap* maps, int Nmax_lds,
+__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds,
                                            int init_stride_N) {
   const int b = Bt.order[blockIdx.x];
   EvalCtx C;
   load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
-  const DevMap M = maps[Bt.map_id[b]];
-  double* pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8]
+  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
+  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8]
   SolveIO S;
-  S.x = Bt.x + (size_t)b * Bt.nmax;
-  S.g = Bt.work + ((size_t)b * 4 + 0) * Bt.nmax;
-  S.xp = Bt.work + ((size_t)b * 4 + 1) * Bt.nmax;
-  S.gp = Bt.work + ((size_t)b * 4 + 2) * Bt.nmax;
-  S.d = Bt.work + ((size_t)b * 4 + 3) * Bt.nmax;
-  S.hist_s = Bt.hist_s + (size_t)b * Bt.hist_m * Bt.nmax;
-  S.hist_y = Bt.hist_y + (size_t)b * Bt.hist_m * Bt.nmax;
-  S.hist_ys = Bt.hist_ys + (size_t)b * Bt.hist_m;
-  S.hist_al = Bt.hist_alpha + (size_t)b * Bt.hist_m;
+  S.x = (glb_dp)(Bt.x + (size_t)b * Bt.nmax);
+  S.g = (glb_dp)(Bt.work + ((size_t)b * 4 + 0) * Bt.nmax);
+  S.xp = (glb_dp)(Bt.work + ((size_t)b * 4 + 1) * Bt.nmax);
+  S.gp = (glb_dp)(Bt.work + ((size_t)b * 4 + 2) * Bt.nmax);
+  S.d = (glb_dp)(Bt.work + ((size_t)b * 4 + 3) * Bt.nmax);
+  S.hist_s = (glb_dp)(Bt.hist_s + (size_t)b * Bt.hist_m * Bt.nmax);
+  S.hist_y = (glb_dp)(Bt.hist_y + (size_t)b * Bt.hist_m * Bt.nmax);
+  S.hist_ys = (glb_dp)(Bt.hist_ys + (size_t)b * Bt.hist_m);
+  S.hist_al = (glb_dp)(Bt.hist_alpha + (size_t)b * Bt.hist_m);
   S.nstride = Bt.nmax;
-  S.stats = Bt.stats + (size_t)b * 8;
-  S.trace = Bt.trace ? Bt.trace + (size_t)b * Bt.trace_cap : nullptr;
+  S.stats = (glb_ip)(Bt.stats + (size_t)b * 8);
+  S.trace = Bt.trace ? (glb_dp)(Bt.trace + (size_t)b * Bt.trace_cap) : (glb_dp)nullptr;
   S.trace_cap = Bt.trace_cap;
   // x <- x0
   {
@@ -104,7 +116,7 @@ __device__ __forceinline__ void solve_body(const DevParams& P, const DevBatch& B
   }
   int success = 0;
   double cost = 0.0;
-  solve_trajectory<RMAX>(C, P, M, S, Bt.s1_past[b], pf, success, cost);
+  solve_trajectory<RMAX>(C, mp, S, Bt.s1_past[b], pf, success, cost);
   // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
   __syncthreads();
   const int N = C.N, rows = C.rows;
@@ -123,17 +135,17 @@ __device__ __forceinline__ void solve_body(const DevParams& P, const DevBatch& B
   }
 }
 
-__global__ void __launch_bounds__(64) k_solve1(DevParams P, DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<1>(P, Bt, maps, Nmax_lds, TOPAY_MAX_N);
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<1>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
-__global__ void __launch_bounds__(64) k_solve2(DevParams P, DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<2>(P, Bt, maps, Nmax_lds, TOPAY_MAX_N);
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<2>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
-__global__ void __launch_bounds__(64) k_eval1(DevParams P, DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<1>(P, Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
-__global__ void __launch_bounds__(64) k_eval2(DevParams P, DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<2>(P, Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval2(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<2>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 
 // test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
@@ -210,6 +222,14 @@ struct topay_ctx {
 static void make_dev_params(const topay_params_t& p, DevParams& d) {
   memset(&d, 0, sizeof(d));
   d.relu_mu = p.relu_mu;
+  {
+    const double pe = p.relu_mu;
+    d.sl_half = 0.5 * pe;
+    d.sl_f3c = 1.0 / (pe * pe);
+    d.sl_f4c = -0.5 * d.sl_f3c / pe;
+    d.sl_d2c = 3.0 * d.sl_f3c;
+    d.sl_d3c = 4.0 * d.sl_f4c;
+  }
   for (int i = 0; i < 9; i++) d.energy_weights[i] = p.energy_weights[i];
   d.s1_time_weight = p.s1_time_weight; d.s1_moment_weight = p.s1_moment_weight; d.s1_acc_weight = p.s1_acc_weight;
   d.s1_domega_weight = p.s1_domega_weight; d.s1_path_pos_weight = p.s1_path_pos_weight;
@@ -381,8 +401,8 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   }
   m.res = desc->resolution;
   m.res_inv = 1.0 / desc->resolution;  // grid_map.cpp:41
-  m.esdf2d = c->map2d[map_id].as<double>();
-  m.esdf3d = c->map3d[map_id].as<double>();
+  m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
+  m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
   c->have_map[map_id] = 1;
   HIPCHK(hipMemcpy((char*)c->dmaps.p + sizeof(DevMap) * map_id, &c->hmaps[map_id], sizeof(DevMap), hipMemcpyHostToDevice));
   return TOPAY_OK;
@@ -390,10 +410,18 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
 
 static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8) * sizeof(double); }
 
+static topay_status push_params(topay_ctx* c) {
+  // contexts of one process may carry different parameters: refresh the constant block before every launch
+  HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_P), &c->dp, sizeof(DevParams), 0, hipMemcpyHostToDevice, c->stream));
+  return TOPAY_OK;
+}
+
 static topay_status run_init(topay_ctx* c) {
   const int B = c->B;
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
   const int scratch_stride = (3 * c->Pmax + 1 + TOPAY_MAX_N) * ND;
-  hipLaunchKernelGGL(k_init, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, c->db, c->paths.as<double>(),
+  hipLaunchKernelGGL(k_init, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->db, c->paths.as<double>(),
                      c->path_off.as<long long>(), c->path_len.as<int>(), c->bvel.as<double>(), c->bacc.as<double>(),
                      c->scratch.as<double>(), scratch_stride, TOPAY_MAX_N, 10 * TOPAY_MAX_N - 8);
   HIPCHK(hipGetLastError());
@@ -522,13 +550,15 @@ static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, Args... args) {
   // class 2 (11..21 pieces, two system rows per lane) first: the longest jobs
   const int n2 = (int)c->order2.size(), n1 = (int)c->order1.size();
   int launches = 0;
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
   if (n2 > 0) {
     int nm = 0;
     for (int b : c->order2) nm = std::max(nm, c->hN[b]);
     DevBatch d = c->db;
     const size_t lds = solve_lds_bytes(nm);
     HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k2, dim3(n2), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, args..., nm);
+    hipLaunchKernelGGL(k2, dim3(n2), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
     HIPCHK(hipGetLastError());
     launches++;
   }
@@ -539,7 +569,7 @@ static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, Args... args) {
     d.order = c->db.order + n2;
     const size_t lds = solve_lds_bytes(nm);
     HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k1, dim3(n1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, args..., nm);
+    hipLaunchKernelGGL(k1, dim3(n1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
     HIPCHK(hipGetLastError());
     launches++;
   }
@@ -642,12 +672,13 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   DevBatch d = c->db;
   d.order = tmp.as<int>();
   const size_t lds = solve_lds_bytes(N);
+  if ((s = push_params(c)) != TOPAY_OK) return s;
   if (N <= 10) {
     HIPCHK(hipFuncSetAttribute((const void*)k_eval1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_eval1, dim3(1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+    hipLaunchKernelGGL(k_eval1, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
   } else {
     HIPCHK(hipFuncSetAttribute((const void*)k_eval2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_eval2, dim3(1), dim3(64), lds, c->stream, c->dp, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+    hipLaunchKernelGGL(k_eval2, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -14,31 +14,33 @@
 namespace topay {
 
 struct SolveIO {
-  double* x;       // [n] decision vector (in: x0, out: final)
-  double* g;       // [n]
-  double* xp;      // [n]
-  double* gp;      // [n]
-  double* d;       // [n]
-  double* hist_s;  // [m][nstride]
-  double* hist_y;  // [m][nstride]
-  double* hist_ys; // [m]
-  double* hist_al; // [m]
+  glb_dp x;        // [n] decision vector (in: x0, out: final)
+  glb_dp g;        // [n]
+  glb_dp xp;       // [n]
+  glb_dp gp;       // [n]
+  glb_dp d;        // [n]
+  glb_dp hist_s;   // [m][nstride]
+  glb_dp hist_y;   // [m][nstride]
+  glb_dp hist_ys;  // [m]  1 / (y.s)
+  glb_dp hist_al;  // [m]
   int nstride;
-  int* stats;      // [8]
-  double* trace;   // optional f-per-evaluation trace
+  glb_ip stats;    // [8]
+  glb_dp trace;    // optional f-per-evaluation trace
   int trace_cap;
 };
 
-__device__ __forceinline__ double vec_dot(const double* a, const double* b, int n, int lane) {
+__device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane) {
   double s = 0.0;
   for (int e = lane; e < n; e += 64) s += a[e] * b[e];
   return wave_sum(s);
 }
 
 template <int RMAX>
-__device__ __forceinline__ void solve_trajectory(EvalCtx& C, const DevParams& P, const DevMap& M, SolveIO& S, int s1_past,
-                                                 double* pf /* LDS [8] */, int& success_out, double& cost_out) {
+__device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
+                                                 lds_dp pf /* LDS [8] */, int& success_out, double& cost_out) {
+  const DevParams& P = g_P;
   const int lane = C.lane, n = C.n;
+  constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
   int stage = 1;
   int alm_iter = 0;
   bool success = false;
@@ -63,11 +65,14 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const DevParams& P,
     const int mem = lp.mem_size;
     // ------------------------------------------------------------------ evaluate at x
     __syncthreads();
+    STAMP(C, 9);  // L-BFGS bookkeeping between evaluations
     double f;
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, P, M);
-    else f = eval_cost_grad<2, RMAX>(C, P, M);
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp);
+    else f = eval_cost_grad<2, RMAX>(C, mp);
     evals++;
+#ifndef TOPAY_STAMPS
     if (S.trace && lane == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;
+#endif
     ntrace++;
 
     enum { GO_EVAL = 0, GO_LS_BEGIN = 1, GO_RUN_END = 2 };
@@ -167,8 +172,8 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const DevParams& P,
         } else {
           ++k;
           // s = x - xp, y = g - gp; ys, yy, |s|^2, |gp|^2 — lbfgs.hpp:647-677
-          double* sE = S.hist_s + (size_t)end * S.nstride;
-          double* yE = S.hist_y + (size_t)end * S.nstride;
+          glb_dp sE = S.hist_s + (size_t)end * S.nstride;
+          glb_dp yE = S.hist_y + (size_t)end * S.nstride;
           double ys = 0.0, yy = 0.0, ss = 0.0, gg = 0.0;
           for (int e = lane; e < n; e += 64) {
             const double se = S.x[e] - S.xp[e], ye = S.g[e] - S.gp[e], gpe = S.gp[e];
@@ -178,32 +183,95 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const DevParams& P,
             S.d[e] = -S.g[e];
           }
           ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gg = wave_sum(gg);
-          S.hist_ys[end] = ys;  // every lane stores the same value; each lane later reads its own store
+          // 1/ys is stored instead of ys: one division per iteration instead of two per history pair.
+          // Every lane stores the same value; each lane later reads back its own store.
+          S.hist_ys[end] = 1.0 / ys;
           const double cau = ss * sqrt(gg) * lp.cautious_factor;
           if (ys > cau) {
             ++bound;
             bound = mem < bound ? mem : bound;
             end = (end + 1) % mem;
             if (stage == 2) st_sumb += bound;
-            int j = end;
-            for (int i = 0; i < bound; ++i) {
-              j = (j + mem - 1) % mem;
-              const double* sj = S.hist_s + (size_t)j * S.nstride;
-              const double* yj = S.hist_y + (size_t)j * S.nstride;
-              const double al = vec_dot(sj, S.d, n, lane) / S.hist_ys[j];
-              S.hist_al[j] = al;
-              for (int e = lane; e < n; e += 64) S.d[e] += (-al) * yj[e];
+            // two-loop recursion (lbfgs.hpp:691-710) with the direction held in registers (element e = lane + 64 t).
+            // History pairs stream from HBM through a PF-deep register ring so that PF loads are always in flight
+            // while the dependent dot-product / axpy chain runs.
+            constexpr int PF = 4;
+            SUBSTAMP_BEGIN(C);
+            double dr[EPL];
+#pragma unroll
+            for (int t = 0; t < EPL; t++) {
+              const int e = lane + 64 * t;
+              dr[t] = e < n ? -S.g[e] : 0.0;
             }
-            const double sc = ys / yy;
-            for (int e = lane; e < n; e += 64) S.d[e] *= sc;
-            for (int i = 0; i < bound; ++i) {
-              const double* sj = S.hist_s + (size_t)j * S.nstride;
-              const double* yj = S.hist_y + (size_t)j * S.nstride;
-              const double beta = vec_dot(yj, S.d, n, lane) / S.hist_ys[j];
-              const double co = S.hist_al[j] - beta;
-              for (int e = lane; e < n; e += 64) S.d[e] += co * sj[e];
-              j = (j + 1) % mem;
+            double sb[PF][EPL], yb[PF][EPL], rb[PF], ab[PF];
+            // ---- first loop: newest pair first.  Pair index of step i: (end - 1 - i) mod mem
+            auto load_pair = [&](int slot, int jj, bool with_alpha) {
+              glb_cdp sj = S.hist_s + (size_t)jj * S.nstride;
+              glb_cdp yj = S.hist_y + (size_t)jj * S.nstride;
+#pragma unroll
+              for (int t = 0; t < EPL; t++) {
+                const int e = lane + 64 * t;
+                sb[slot][t] = e < n ? sj[e] : 0.0;
+                yb[slot][t] = e < n ? yj[e] : 0.0;
+              }
+              rb[slot] = S.hist_ys[jj];
+              if (with_alpha) ab[slot] = S.hist_al[jj];
+            };
+            int jl = end;  // next pair to load (walks down, wrapping)
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+              if (u < bound) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl, false); }
+            int jlast = end, jc = end;  // jc: pair being processed
+            for (int i0 = 0; i0 < bound; i0 += PF) {
+#pragma unroll
+              for (int u = 0; u < PF; u++) {
+                const int i = i0 + u;
+                if (i < bound) {
+                  jc = jc == 0 ? mem - 1 : jc - 1;
+                  const int j = jc;
+                  double part = 0.0;
+#pragma unroll
+                  for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
+                  const double al = wave_sum(part) * rb[u];
+                  S.hist_al[j] = al;
+#pragma unroll
+                  for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
+                  jlast = j;
+                  if (i + PF < bound) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl, false); }
+                }
+              }
             }
+            const double scl = ys / yy;
+#pragma unroll
+            for (int t = 0; t < EPL; t++) dr[t] *= scl;
+            // ---- second loop: oldest pair first.  Pair index of step i: (jlast + i) mod mem
+            __syncthreads();  // alpha values were stored by every lane; make sure they are back before re-reading
+            jl = jlast;  // next pair to load (walks up, wrapping)
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+              if (u < bound) { load_pair(u, jl, true); jl = jl + 1 == mem ? 0 : jl + 1; }
+            for (int i0 = 0; i0 < bound; i0 += PF) {
+#pragma unroll
+              for (int u = 0; u < PF; u++) {
+                const int i = i0 + u;
+                if (i < bound) {
+                  double part = 0.0;
+#pragma unroll
+                  for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
+                  const double beta = wave_sum(part) * rb[u];
+                  const double co = ab[u] - beta;
+#pragma unroll
+                  for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
+                  if (i + PF < bound) { load_pair(u, jl, true); jl = jl + 1 == mem ? 0 : jl + 1; }
+                }
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < EPL; t++) {
+              const int e = lane + 64 * t;
+              if (e < n) S.d[e] = dr[t];
+            }
+            SUBSTAMP_END(C, 10);  // two-loop recursion
           }
           step = 1.0;
           go = GO_LS_BEGIN;

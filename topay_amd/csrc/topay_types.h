@@ -9,14 +9,30 @@
 #define TOPAY_MAX_N 21      // 6N <= 128 rows = 2 rows per lane
 #define TOPAY_WAVE 64
 
+// Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
+// functions; as plain generic pointers every access becomes a FLAT instruction with a full vmcnt/lgkmcnt drain.
+// With the qualifiers the compiler emits ds_* for LDS and global_* for HBM.  The CPU lane-emulator build of
+// these sources defines both away on its command line.
+#ifndef TOPAY_LDS
+#define TOPAY_LDS __attribute__((address_space(3)))
+#endif
+#ifndef TOPAY_GLB
+#define TOPAY_GLB __attribute__((address_space(1)))
+#endif
+typedef TOPAY_LDS double* lds_dp;
+typedef const TOPAY_LDS double* lds_cdp;
+typedef TOPAY_GLB double* glb_dp;
+typedef const TOPAY_GLB double* glb_cdp;
+typedef TOPAY_GLB int* glb_ip;
+
 struct DevMap {
   double origin[3];
   double res, res_inv;
   double min_b[3], max_b[3];
   int dims[3];
   int pad;
-  const double* esdf2d;
-  const double* esdf3d;
+  glb_cdp esdf2d;
+  glb_cdp esdf3d;
 };
 
 struct DevLbfgs {
@@ -26,6 +42,8 @@ struct DevLbfgs {
 
 struct DevParams {
   double relu_mu;
+  // smoothL1Penalty constants (moma_traj_opt.h:812-817), evaluated once on the host exactly as the reference does per call
+  double sl_half, sl_f3c, sl_f4c, sl_d2c, sl_d3c;
   double energy_weights[9];
   double s1_time_weight, s1_moment_weight, s1_acc_weight, s1_domega_weight, s1_path_pos_weight;
   double s2_time_weight, s2_moment_weight, s2_acc_weight, s2_domega_weight;
