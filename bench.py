@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: candidate trajectories optimised to L-BFGS convergence per second (BASELINE.json metric).
+
+Workload ("benchmark_tables batch"): S independent 'tables' scenarios per GPU, each with its own freshly generated map
+(the reference's benchmark loop regenerates the map every episode, src/planner/src/planner.cpp:514-521) and 8 topological
+candidate init paths (the reference's cap, planner.cpp:59,829).  One step = the whole hot path over the batch, starting
+from inputs resident in HBM: the init kernel (optimizeTraj lines 146-357) + the persistent solve kernel (lines 359-497:
+stage-1 L-BFGS, stage-2 ALM loop) + the gather of per-scenario result records (RCCL all-gather when N > 1).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 3 --warmup 1
+
+Scaling is weak: every rank owns S scenarios (different seeds); no collective inside the solve.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(stats, n_pieces):
+    """Algorithmic bytes of one solve of the batch (no cache credit), DESIGN.md "Roofline accounting":
+       stage-2 evaluation of N pieces  : 13N x (4 + 12*8) ESDF doubles + coefficients/gradient in/out = 11 280 N B
+       stage-1 evaluation              : coefficients + T in, gdC + gdT out                          =    880 N B
+       accepted L-BFGS iteration       : two-loop reads 4 x bound x n x 8 B (bound summed by the solver) + history
+                                         write 2n x 8 B + x, g, d, xp, gp traffic ~ 10n x 8 B
+    """
+    N = n_pieces.astype(np.float64)
+    n = 10.0 * N - 8.0
+    ev1, ev2 = stats[:, 2].astype(np.float64), stats[:, 5].astype(np.float64)
+    it = (stats[:, 1] + stats[:, 4]).astype(np.float64)
+    sumb = stats[:, 7].astype(np.float64)
+    b = ev2 * 11280.0 * N + ev1 * 880.0 * N + sumb * 4.0 * n * 8.0 + it * 12.0 * n * 8.0
+    return float(b.sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenarios", type=int, default=512, help="scenarios per GPU (x 8 candidates each)")
+    ap.add_argument("--candidates", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=768, help="trajectories of the batch timed on the host cores")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    from topay_amd import api, dist as tdist
+    from topay_amd.harness import workload as wl
+
+    # ---- synthetic inputs (CPU harness, untimed): S scenarios of this rank, one map each
+    S, Ccand = args.scenarios, args.candidates
+    t0 = time.time()
+    tb = wl.TablesBatch(S, Ccand, base_seed=42 + rank * 100000, nthreads=0)
+    B = len(tb.lens)
+    opt = api.MomaTrajOptBatch(device=local_rank)
+    slot = {}
+    for k, s in enumerate(tb.scenarios):
+        w = tb.world(s)
+        opt.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, map_id=k)
+        slot[s] = k
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+    opt.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)   # raw init paths + maps now resident in HBM
+    n_pieces = opt.n_pieces()
+    setup_s = time.time() - t0
+    scen_global = tb.scen.astype(np.int64) + rank * S
+    scen_ids = np.array(sorted(set(scen_global.tolist())), dtype=np.int64)
+
+    def step():
+        opt.reset()                      # init kernel from the resident raw paths (optimizeTraj:146-357)
+        ok = opt.optimize()              # persistent solve kernel (optimizeTraj:359-497), syncs its stream
+        ms, _ = opt.last_kernel_ms()
+        if distributed:                  # the one exchange of the path: per-scenario result records over RCCL
+            st_ = opt.stats()
+            dur = np.zeros(B)
+            recs = tdist.scenario_records(scen_ids, scen_global, ok.astype(np.int32), opt.traj_cost, n_pieces, dur)
+            tdist.gather_records(recs, max_rows=S, device=dev)
+        return ok, ms
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    kernel_ms = []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        ok, ms = step()
+        kernel_ms.append(ms)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tot = torch.tensor([float(B)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_traj = float(tot.item())
+    else:
+        total_traj = float(B)
+
+    stats = opt.stats()
+    abytes = algorithmic_bytes(stats, n_pieces)
+    kms = float(np.mean(kernel_ms))
+    achieved = abytes / (kms * 1e-3) / 1e9
+    out = {
+        "metric": "trajectories/sec to L-BFGS convergence (benchmark_tables batch)",
+        "value": total_traj * args.steps / elapsed,
+        "unit": "trajectories/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"benchmark_tables batch: {S} scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, "
+                        "tables map 20x20x1.6 m @0.1 m regenerated per scenario, both stages + ALM to convergence",
+            "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
+            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory",
+            "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
+            "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
+            "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
+            "setup_seconds_untimed": setup_s,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k_solve1/k_solve2 (persistent per-trajectory solve)", "kernel_ms": kms,
+            "algorithmic_bytes_per_step": abytes,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (a port of the reference path; the reference itself needs Eigen/ROS and cannot be
+        # built) on the host cores of this box, thread pool with one trajectory per task, bounded sample of the batch.
+        from oracle import oracle as orc
+
+        cores = os.cpu_count() or 1
+        nsamp = min(args.cpu_sample, B)
+        # whole scenarios only, each against its own map: run per scenario group through one batch call per map
+        offs = np.concatenate([[0], np.cumsum(tb.lens)])
+        t_cpu = 0.0
+        done = 0
+        succ = 0
+        # group consecutive trajectories by scenario; solve groups in one pool by launching per-map batches from
+        # worker threads would need per-map handles, so scenarios are processed in chunks with all cores each
+        import concurrent.futures as cf
+
+        groups = []
+        b = 0
+        while b < nsamp:
+            e = b
+            while e < B and tb.scen[e] == tb.scen[b]:
+                e += 1
+            groups.append((b, e))
+            b = e
+        per_group_threads = max(1, min(cores, 8))
+        workers = max(1, cores // per_group_threads)
+
+        def run_group(be):
+            b0, e0 = be
+            w = tb.world(int(tb.scen[b0]))
+            m = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
+            r = orc.optimize_batch(m, tb.lens[b0:e0], tb.paths[offs[b0]:offs[e0]], nthreads=per_group_threads)
+            return int(r["success"].sum()), e0 - b0
+
+        t1 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+            for s_, n_ in ex.map(run_group, groups):
+                succ += s_
+                done += n_
+        t_cpu = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": done / t_cpu, "unit": "trajectories/s", "cores": min(cores, workers * per_group_threads),
+            "kind": "port",
+            "sample": f"first {done} trajectories ({len(groups)} scenarios) of the same batch, CPU oracle (C++ port of "
+                      f"the reference path), {workers} x {per_group_threads} threads, {t_cpu:.1f} s wall, "
+                      f"success {succ / max(done, 1):.3f}",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

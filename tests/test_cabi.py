@@ -1,0 +1,70 @@
+"""The drop-in boundary: the hipcc-built library exists, exports every symbol include/topay.h declares, its
+parameter block has the reference defaults, and without a usable HIP device it fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+from topay_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    entry.build_hip()  # hipcc cross-compiles for gfx950 without a GPU
+    return api.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "topay.h")).read()
+    # function declarations look like "topay_status topay_xxx(" / "void topay_destroy(" / "const char* topay_last_error("
+    return sorted(set(re.findall(r"^(?:topay_status|void|const char\*)\s+(topay_[a-z0-9_]+)\s*\(", text, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/topay.h but not exported"
+
+
+def test_default_params_are_the_reference_values(hip_lib):
+    p = api.default_params(hip_lib)
+    assert p.int_K == 12 and p.min_piece_num == 3 and p.relu_mu == 1e-3 and p.sample_interval == 1.5
+    assert list(p.energy_weights) == [0.33] + [1.0] * 8
+    assert (p.s1_time_weight, p.s1_path_pos_weight, p.s1_normal_past, p.s1_shot_path_past) == (20.0, 2e5, 2, 8)
+    assert (p.s1_lbfgs.mem_size, p.s1_lbfgs.delta, p.s1_lbfgs.max_iterations) == (256, 1e-2, 8000)
+    assert (p.s2_lbfgs.mem_size, p.s2_lbfgs.past, p.s2_lbfgs.delta, p.s2_lbfgs.min_step) == (256, 3, 1e-4, 1e-32)
+    assert (p.s2_collision_weight, p.s2_mean_time_weight, p.s2_time_weight) == (5e5, 5000.0, 50.0)
+    assert list(p.alm_init_rho) == [1e4, 1e4] and p.alm_tolerance == 0.01
+    assert (p.max_v, p.max_a, p.max_w, p.max_dw) == (1.0, 0.8, 1.25, 1.0)
+    assert min(r for r in p.colli_point_radius if r > 0) == 0.055  # moma_param.h:110-112 floor
+
+
+def test_unsupported_parameters_are_rejected(hip_lib):
+    p = api.default_params(hip_lib)
+    p.int_K = 32
+    h = C.c_void_p()
+    assert hip_lib.topay_create(C.byref(p), 0, C.byref(h)) == -6  # TOPAY_ERR_UNSUPPORTED
+
+
+def test_no_device_means_loud_failure(hip_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = api.default_params(hip_lib)
+    h = C.c_void_p()
+    st = hip_lib.topay_create(C.byref(p), 0, C.byref(h))
+    assert st == -2  # TOPAY_ERR_NO_DEVICE
+    assert b"no CPU fallback" in hip_lib.topay_last_error() or b"hip" in hip_lib.topay_last_error().lower()
+    with pytest.raises(api.TopayError):
+        api.MomaTrajOptBatch()
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(api.TopayError):
+        api.load(str(tmp_path / "libtopay_hip.so"))

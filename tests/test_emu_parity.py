@@ -1,0 +1,99 @@
+"""Kernel logic vs the oracle on the CPU: the HIP kernel sources are compiled unmodified with g++ against the
+lane emulator in tests/emu (test infrastructure, never a product fallback) and driven through the same C-ABI.
+Per-evaluation parity is tight (~1e-13); whole solves are compared only while the reference's chaotic stage-2
+iteration has not yet amplified rounding differences (capped iterations), see DESIGN.md "Parity"."""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, set_map
+from oracle import oracle as orc
+from topay_amd import api
+
+
+@pytest.fixture(scope="module")
+def emu(cuboids_small):
+    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(opt, cuboids_small["world"])
+    opt.set_init_traj(cuboids_small["lens"], cuboids_small["paths"])
+    return opt
+
+
+def test_init_traj_matches_oracle(emu, cuboids_small):
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    Ns = emu.n_pieces()
+    for b in range(len(cs["lens"])):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        assert Ns[b] == o.N and n == 10 * o.N - 8
+        assert np.allclose(emu.get_x(b), o.get_x(), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_eval_matches_oracle(emu, cuboids_small, stage):
+    cs = cuboids_small
+    rng = np.random.default_rng(stage)
+    o = orc.Oracle(cs["map"])
+    for b in range(len(cs["lens"])):  # N = 4..11: both row classes (one / two system rows per lane)
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        for trial in range(2):
+            x = o.get_x() + (0.05 * rng.standard_normal(n) if trial else 0.0)
+            lam, rho = [0.3, -0.2], [1e4, 2e4]
+            o.set_alm(lam, rho)
+            f, g = o.eval(stage, x)
+            fe, ge, e = emu.eval(stage, b, x, lam, rho)
+            assert abs(f - fe) <= 1e-12 * abs(f)
+            assert np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+            if stage == 2:
+                assert np.allclose(e, o.final_xy_error(), atol=1e-12)
+
+
+def test_eval_rare_paths_match_oracle(emu, cuboids_small):
+    """Much shorter pieces switch on the joint velocity / acceleration limits (gradBeta rows 1 and 2 of the joints,
+    moma_traj_opt.cpp:1674-1710) and the mean-time band; folded joints switch on self collision terms."""
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    for b in range(len(cs["lens"])):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        N = o.N
+        x = o.get_x().copy()
+        x[:N] -= 1.6
+        x[N - 1] += 2.5  # one long piece: mean-time band
+        x[3 * N - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], N - 1)  # fold the arm
+        o.set_alm([0, 0], [1e4, 1e4])
+        f, g = o.eval(2, x)
+        t = o.debug_terms()
+        assert t["mani_vel"] > 0 and t["mani_acc"] > 0 and t["mean_time"] > 0
+        fe, ge, _ = emu.eval(2, b, x, [0, 0], [1e4, 1e4])
+        assert abs(f - fe) <= 1e-12 * abs(f)
+        assert np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+    assert t["self_colli"] >= 0
+
+
+def test_capped_solve_matches_oracle(cuboids_small):
+    """Stage 1 in full and the first stage-2 iterations: same iteration/evaluation counts, same iterate."""
+    cs = cuboids_small
+    p = api.default_params(api.load(EMU_LIB))
+    p.s2_lbfgs.max_iterations = 12
+    p.alm_max_outer = 1
+    opt = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(opt, cs["world"])
+    sel = [0, 1, 5]
+    lens = cs["lens"][sel]
+    paths = np.concatenate([cs["paths"][cs["offs"][i]:cs["offs"][i + 1]] for i in sel])
+    opt.optimizeTraj(lens, paths)
+    st = opt.stats()
+    for k, b in enumerate(sel):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s2_max_iterations", 12)
+        o.set_param("alm_max_outer", 1)
+        o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        o.optimize()
+        so = o.stats()
+        assert list(st[k][:7]) == [so[key] for key in api.STAT_KEYS[:7]]
+        assert st[k][7] == so["sum_bound"]
+        assert np.allclose(opt.get_x(k), o.get_x(), rtol=1e-7, atol=1e-8)
+        assert abs(opt.traj_cost[k] - o.traj_cost()) <= 1e-8 * abs(o.traj_cost())
+        tr = opt.getTraj(k)
+        d, c, kn = o.get_traj()
+        assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["coeffs"], c, rtol=1e-6, atol=1e-7)
+        assert np.allclose(tr["knots_xy"], kn, atol=1e-7)

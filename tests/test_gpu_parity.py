@@ -1,0 +1,199 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C-ABI (topay_amd/lib/libtopay_hip.so).
+
+Three layers, from tight to loose (DESIGN.md "Parity"):
+  1. per evaluation, HIP vs the independent oracle: cost and gradient to ~1e-13 (asserted at 1e-11/1e-10);
+  2. whole solves, HIP vs the CPU lane-emulator build of the same kernel sources: BIT-IDENTICAL iterates, evaluation
+     traces and results (the reference's stage-2 L-BFGS is chaotically sensitive to rounding, so bit-exact arithmetic
+     is the only way converged results can be reproduced at all);
+  3. whole solves, HIP vs oracle: identical while rounding has not yet been amplified (capped iterations, 1e-7), and
+     statistically equivalent at convergence (success rate, end-point error, cost distribution); plus size-independent
+     properties at full batch size.
+"""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, set_map
+from oracle import oracle as orc
+from topay_amd import api
+from topay_amd.harness import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(cuboids_small):
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, cuboids_small["world"])
+    opt.set_init_traj(cuboids_small["lens"], cuboids_small["paths"])
+    return opt
+
+
+@pytest.fixture(scope="module")
+def emu(cuboids_small):
+    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(opt, cuboids_small["world"])
+    opt.set_init_traj(cuboids_small["lens"], cuboids_small["paths"])
+    return opt
+
+
+def test_deterministic_math_is_bitwise_equal_to_cpu(gpu, emu):
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(-10, 10, 20000), rng.uniform(-1e5, 1e5, 5000), rng.uniform(-1e-3, 1e-3, 1000),
+                        [0.0, np.pi / 2, -np.pi, 1e6, 1e12]])
+    b = rng.uniform(-10, 10, len(a))
+    mg, me = gpu.test_math(a, b), emu.test_math(a, b)
+    assert (mg == me).all()
+    assert np.abs(mg[:, 0] - np.sin(a)).max() < 3e-16 * 4 and np.abs(mg[:, 2] - np.arctan2(a, b)).max() < 1e-15
+
+
+def test_init_traj_matches_oracle(gpu, cuboids_small):
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    Ns = gpu.n_pieces()
+    for b in range(len(cs["lens"])):
+        o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        assert Ns[b] == o.N
+        assert np.allclose(gpu.get_x(b), o.get_x(), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_eval_matches_oracle_and_emulator(gpu, emu, cuboids_small, stage):
+    cs = cuboids_small
+    rng = np.random.default_rng(10 + stage)
+    o = orc.Oracle(cs["map"])
+    for b in range(len(cs["lens"])):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        N = o.N
+        for trial in range(3):
+            x = o.get_x().copy()
+            if trial == 1:
+                x += 0.05 * rng.standard_normal(n)
+            if trial == 2:  # rare paths: joint velocity/acceleration limits, mean-time band, folded arm
+                x[:N] -= 1.6
+                x[N - 1] += 2.5
+                x[3 * N - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], N - 1)
+            lam, rho = [0.3, -0.2], [1e4, 2e4]
+            o.set_alm(lam, rho)
+            f, g = o.eval(stage, x)
+            fg, gg, eg = gpu.eval(stage, b, x, lam, rho)
+            fe, ge, ee = emu.eval(stage, b, x, lam, rho)
+            # tolerance of the floating-point parity claim: 1e-11 relative on f, 1e-10 of max|g| on g (observed ~1e-14)
+            assert abs(f - fg) <= 1e-11 * abs(f)
+            assert np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
+            assert fg == fe and (gg == ge).all() and (eg == ee).all()  # bit-identical to the CPU execution
+
+
+def test_golden_fixture_evaluations(gpu):
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cuboids_seed42.npz"))
+    for b in range(len(gold["lens"])):
+        for stage in (1, 2):
+            f, g, _ = gpu.eval(stage, b, gold[f"x_{b}"], gold[f"lam_{b}"], gold[f"rho_{b}"])
+            assert abs(f - gold[f"f{stage}_{b}"]) <= 1e-11 * abs(f)
+            assert np.abs(g - gold[f"g{stage}_{b}"]).max() <= 1e-10 * np.abs(g).max()
+
+
+def test_full_solve_is_bit_identical_to_emulator(cuboids_small):
+    """Complete optimizeTraj (stage 1 + ALM loop) of two candidates: every evaluated cost, the final iterate, the
+    counters and the returned trajectory are identical bit for bit on the GPU and on the CPU."""
+    cs = cuboids_small
+    lens = cs["lens"][:2]
+    paths = cs["paths"][:cs["offs"][2]]
+    res = {}
+    for name, lib in (("gpu", None), ("emu", EMU_LIB)):
+        opt = api.MomaTrajOptBatch(device=0, lib_path=lib)
+        set_map(opt, cs["world"])
+        opt.set_init_traj(lens, paths)
+        opt.set_trace(3000)
+        ok = opt.optimize()
+        res[name] = dict(ok=ok, cost=opt.traj_cost.copy(), stats=opt.stats(), trace=[opt.get_trace(b) for b in range(2)],
+                         x=[opt.get_x(b) for b in range(2)], traj=[opt.getTraj(b) for b in range(2)])
+    g, e = res["gpu"], res["emu"]
+    assert (g["ok"] == e["ok"]).all() and (g["cost"] == e["cost"]).all() and (g["stats"] == e["stats"]).all()
+    for b in range(2):
+        assert (g["trace"][b] == e["trace"][b]).all() and (g["x"][b] == e["x"][b]).all()
+        assert (g["traj"][b]["coeffs"] == e["traj"][b]["coeffs"]).all()
+        assert (g["traj"][b]["knots_xy"] == e["traj"][b]["knots_xy"]).all()
+    assert g["stats"][:, 4].min() > 50  # these are real stage-2 runs, not early exits
+
+
+def test_capped_solve_matches_oracle(cuboids_small):
+    cs = cuboids_small
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 12
+    p.alm_max_outer = 1
+    opt = api.MomaTrajOptBatch(params=p, device=0)
+    set_map(opt, cs["world"])
+    opt.optimizeTraj(cs["lens"], cs["paths"])
+    st = opt.stats()
+    for b in range(len(cs["lens"])):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s2_max_iterations", 12)
+        o.set_param("alm_max_outer", 1)
+        o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        o.optimize()
+        so = o.stats()
+        assert list(st[b]) == [so[k] for k in api.STAT_KEYS]
+        # 1e-7: twelve stage-2 iterations amplify the 1e-14 per-evaluation differences by a few orders of magnitude
+        assert np.allclose(opt.get_x(b), o.get_x(), rtol=1e-7, atol=1e-8)
+        assert abs(opt.traj_cost[b] - o.traj_cost()) <= 1e-8 * abs(o.traj_cost())
+        tr = opt.getTraj(b)
+        d, c, kn = o.get_traj()
+        assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["knots_xy"], kn, atol=1e-7)
+
+
+def test_config2_tables_64_candidates():
+    """BASELINE config 2: one 'tables' scenario x 64 candidates.  Properties of the converged batch + statistical
+    agreement with the CPU oracle (converged values themselves are not comparable one by one: chaotic iteration)."""
+    world, start, goal, lens, paths = wl.tables_scenario(0, 64)
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, world)
+    ok = opt.optimizeTraj(lens, paths)
+    cost = opt.traj_cost.copy()
+    st = opt.stats()
+    assert ok.mean() > 0.8
+    for b in np.nonzero(ok)[0][:16]:
+        tr = opt.getTraj(int(b))
+        assert np.all(tr["durations"] > 0) and np.isfinite(tr["coeffs"]).all()
+        assert np.linalg.norm(tr["knots_xy"][-1] - goal[:2]) < 0.01   # ALM tolerance reached (moma_traj_opt.cpp:451)
+        assert np.allclose(tr["knots_xy"][0], start[:2])
+    # same batch again: identical bits (no atomics, no timing dependence)
+    ok2 = opt.optimizeTraj(lens, paths)
+    assert (ok2 == ok).all() and (opt.traj_cost[ok] == cost[ok]).all() and (opt.stats() == st).all()
+    m = orc.MapView(world.origin, world.res, world.dims, world.min_b, world.max_b, world.esdf2d, world.esdf3d)
+    r = orc.optimize_batch(m, lens, paths, nthreads=16)
+    # stage 1 is short and not chaotic: identical counters
+    assert (st[:, :3] == r["stats"][:, :3]).mean() > 0.95
+    assert abs(ok.mean() - r["success"].mean()) <= 0.1
+    both = ok & (r["success"] == 1)
+    assert abs(np.median(cost[both]) / np.median(r["cost"][both]) - 1.0) < 0.05
+
+
+def test_large_batch_properties_and_multi_map():
+    """Size-independent properties on a larger multi-map batch (32 tables scenarios x 8 candidates, one map each)."""
+    tb = wl.TablesBatch(32, 8, base_seed=1000, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    for k, s in enumerate(tb.scenarios):
+        set_map(opt, tb.world(s), map_id=k)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+    ok = opt.optimizeTraj(tb.lens, tb.paths, map_ids=map_ids)
+    st = opt.stats()
+    assert len(ok) == 256 and ok.mean() > 0.7
+    assert np.isfinite(opt.traj_cost[ok]).all()
+    assert (st[:, 0] == 1).mean() > 0.95          # stage 1 stops on the past/delta test
+    assert (st[ok, 6] >= 1).all() and (st[:, 5] >= st[:, 4]).all()   # at least one ALM round; evals >= iterations
+    # candidates of scenario s evaluated against a different map must differ: spot-check via the eval hook
+    b = int(np.nonzero(map_ids == 1)[0][0])
+    x = opt.get_x(b)
+    world1 = tb.world(tb.scenarios[1])
+    m1 = orc.MapView(world1.origin, world1.res, world1.dims, world1.min_b, world1.max_b, world1.esdf2d, world1.esdf3d)
+    o = orc.Oracle(m1)
+    off = int(np.concatenate([[0], np.cumsum(tb.lens)])[b])
+    o.set_init_traj(tb.paths[off:off + tb.lens[b]])
+    o.set_alm([0, 0], [1e4, 1e4])
+    f, g = o.eval(2, x)
+    fg, gg, _ = opt.eval(2, b, x, [0, 0], [1e4, 1e4])
+    assert abs(f - fg) <= 1e-11 * abs(f) and np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
+    tb.close()

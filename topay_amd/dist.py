@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of independent scenarios (one process per GPU, torch.distributed: "nccl" is RCCL on ROCm).
+
+Every candidate trajectory is independent (own decision vector, own L-BFGS state, read-only map), so there is no
+collective inside the solve.  Scenarios are partitioned over ranks with all candidates of a scenario on one rank,
+so the reference's pick-the-shortest-duration step (src/planner/src/planner.cpp:999-1010) stays local.  The only
+exchange is one all-gather of fixed-size per-scenario result records at the end.
+"""
+import numpy as np
+
+RECORD_FIELDS = ("scenario_id", "best_candidate", "success", "n_pieces", "cost", "duration")
+RECORD_WIDTH = 6  # float64 columns
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition [lo, hi) of n_items over `world` ranks (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durations):
+    """Local argmin-by-duration per scenario -> records [n_scen, 6] (float64).
+    scen_of_traj[b] is the (global) scenario id of trajectory b; durations[b] its total duration."""
+    recs = np.zeros((len(scenario_ids), RECORD_WIDTH))
+    for r, sid in enumerate(scenario_ids):
+        idx = np.nonzero(scen_of_traj == sid)[0]
+        ok = idx[success[idx] > 0]
+        recs[r, 0] = sid
+        if len(ok):
+            best = ok[np.argmin(durations[ok])]
+            recs[r, 1:] = (best - idx[0], 1.0, n_pieces[best], cost[best], durations[best])
+        else:
+            recs[r, 1:] = (-1.0, 0.0, 0.0, np.nan, np.nan)
+    return recs
+
+
+def gather_records(local_records, max_rows, device=None):
+    """All-gather of the per-scenario records (padded to max_rows rows per rank).  Returns the concatenated
+    valid rows on every rank.  Uses the default process group (nccl/RCCL on GPUs, gloo in CPU tests)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    buf = torch.full((max_rows, RECORD_WIDTH + 1), float("nan"), dtype=torch.float64)
+    n = local_records.shape[0]
+    if n:
+        buf[:n, :RECORD_WIDTH] = torch.from_numpy(np.ascontiguousarray(local_records))
+        buf[:n, RECORD_WIDTH] = 1.0  # valid flag
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    rows = torch.cat(out).cpu().numpy()
+    valid = rows[:, RECORD_WIDTH] == 1.0
+    return rows[valid, :RECORD_WIDTH]
