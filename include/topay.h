@@ -147,7 +147,9 @@ topay_status topay_set_map(topay_ctx* ctx, int map_id, const topay_map_desc_t* d
  *   boundary_vel/acc batch x 20, each a 10 x 2 column-major matrix as in the reference
  *                    (row 0 = v, row 1 = omega, rows 3-9 = joints; col 0 = start, col 1 = end); NULL = zeros
  *   map_ids          map slot per candidate, NULL = all slot 0
- * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace. */
+ * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace.
+ * A candidate whose time allocation needs more than 32 pieces (paths longer than ~45 s) cannot be represented by this
+ * build: it is reported as failed (success 0, n_pieces 0) and the rest of the batch is solved normally. */
 topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len, const double* init_paths,
                                  const double* boundary_vel, const double* boundary_acc, const int* map_ids);
 

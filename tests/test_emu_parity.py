@@ -97,3 +97,50 @@ def test_capped_solve_matches_oracle(cuboids_small):
         d, c, kn = o.get_traj()
         assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["coeffs"], c, rtol=1e-6, atol=1e-7)
         assert np.allclose(tr["knots_xy"], kn, atol=1e-7)
+
+
+def _zigzag_path(n_legs, leg=1.3):
+    """Synthetic long init path (inside the 20 x 20 m map) whose time allocation needs many pieces."""
+    pts = [np.array([-8.5, -8.5])]
+    for k in range(n_legs):
+        step = np.array([leg, 0.0]) if k % 2 == 0 else np.array([0.0, leg * (1 if (k // 2) % 2 == 0 else -1)])
+        nxt = pts[-1] + step
+        if abs(nxt[0]) > 8.8:
+            break
+        pts.append(nxt)
+    states = []
+    for k, p in enumerate(pts):
+        th = 0.0 if k == 0 else np.arctan2(*(pts[k] - pts[k - 1])[::-1])
+        q = np.linspace(0.2, -0.3, 7) * (k / max(1, len(pts) - 1))
+        states.append(np.concatenate([p, [th], q]))
+    return np.array(states)
+
+
+def test_three_rows_per_lane_class_and_too_long_paths(cuboids_small):
+    """N in 22..32 uses three system rows per lane; beyond 32 pieces the candidate is reported as failed."""
+    cs = cuboids_small
+    mid = _zigzag_path(17)
+    long_ = _zigzag_path(60, leg=1.35)
+    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(opt, cs["world"])
+    short = cs["paths"][cs["offs"][0]:cs["offs"][1]]
+    lens = np.array([len(mid), len(short), len(long_)], dtype=np.int32)
+    opt.set_init_traj(lens, np.concatenate([mid, short, long_]))
+    N = opt.n_pieces()
+    o = orc.Oracle(cs["map"])
+    o.set_init_traj(mid)
+    assert N[0] == o.N and 22 <= N[0] <= 32, N
+    o_long = orc.Oracle(cs["map"])
+    o_long.set_init_traj(long_)
+    assert o_long.N > 32 and N[2] == 0
+    assert np.allclose(opt.get_x(0), o.get_x(), atol=1e-12)
+    x = o.get_x() + 0.03 * np.random.default_rng(5).standard_normal(o.n)
+    for stage in (1, 2):
+        o.set_alm([0.1, 0.2], [1e4, 1e4])
+        f, g = o.eval(stage, x)
+        fe, ge, _ = opt.eval(stage, 0, x, [0.1, 0.2], [1e4, 1e4])
+        assert abs(f - fe) <= 1e-12 * abs(f) and np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+    with pytest.raises(api.TopayError):
+        opt.get_x(2)
+    r = opt.getTraj(2)
+    assert r["success"] is False and len(r["durations"]) == 0

@@ -43,7 +43,9 @@ def test_deterministic_math_is_bitwise_equal_to_cpu(gpu, emu):
     b = rng.uniform(-10, 10, len(a))
     mg, me = gpu.test_math(a, b), emu.test_math(a, b)
     assert (mg == me).all()
-    assert np.abs(mg[:, 0] - np.sin(a)).max() < 3e-16 * 4 and np.abs(mg[:, 2] - np.arctan2(a, b)).max() < 1e-15
+    small = np.abs(a) <= 1e5  # accuracy range the solver needs; beyond it only bit-reproducibility matters
+    assert np.abs(mg[small, 0] - np.sin(a[small])).max() < 2.5e-16 and np.abs(mg[small, 1] - np.cos(a[small])).max() < 2.5e-16
+    assert np.abs(mg[:, 2] - np.arctan2(a, b)).max() < 1e-15
 
 
 def test_init_traj_matches_oracle(gpu, cuboids_small):

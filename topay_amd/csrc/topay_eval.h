@@ -779,7 +779,7 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 
 // ---------------------------------------------------------------------------------------------
 // The evaluation.  STAGE = 1: firstStageCostCallback; STAGE = 2: secondStageCostCallback.
-// RMAX = rows per lane (1: N <= 10, 2: N <= 21).  Returns f (wave-uniform); writes g[n].
+// RMAX = system rows per lane (1: N <= 10, 2: N <= 21, 3: N <= 32).  Returns f (wave-uniform); writes g[n].
 // ---------------------------------------------------------------------------------------------
 template <int STAGE, int RMAX>
 __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp) {

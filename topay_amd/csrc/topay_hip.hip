@@ -141,11 +141,18 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve1(DevBatch Bt, 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
   solve_body<2>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<3>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval2(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<2>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+}
+
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval3(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<3>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 
 // test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
@@ -207,7 +214,7 @@ struct topay_ctx {
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
   // batch
   int B = 0, Nmax = 0, nmax = 0, total_states = 0, Pmax = 0;
-  std::vector<int> hN, order1, order2;  // per-trajectory N; launch orders of the two row classes
+  std::vector<int> hN, cls[3];  // per-trajectory N (0 = not representable, skipped); launch order of each row class
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
@@ -489,9 +496,10 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   HIPCHK(hipMemcpy(c->hN.data(), c->N.p, (size_t)batch * 4, hipMemcpyDeviceToHost));
   int Nmax = 0;
   for (int b = 0; b < batch; b++) {
-    if (c->hN[b] <= 0) { set_err("a trajectory needs more pieces than TOPAY_MAX_N"); return TOPAY_ERR_TOO_MANY_PIECES; }
+    if (c->hN[b] <= 0) c->hN[b] = 0;  // needs more than TOPAY_MAX_N pieces: reported as failed, never launched
     Nmax = std::max(Nmax, c->hN[b]);
   }
+  if (Nmax == 0) { set_err("every trajectory needs more pieces than TOPAY_MAX_N"); return TOPAY_ERR_TOO_MANY_PIECES; }
   c->Nmax = Nmax;
   c->nmax = 10 * Nmax - 8;
   const int m = std::max(c->hp.s1_lbfgs.mem_size, c->hp.s2_lbfgs.mem_size);
@@ -499,12 +507,18 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   std::vector<int> idx(batch);
   std::iota(idx.begin(), idx.end(), 0);
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) { return c->hN[a] > c->hN[b2]; });
-  c->order1.clear();
-  c->order2.clear();
-  for (int b : idx) (c->hN[b] <= 10 ? c->order1 : c->order2).push_back(b);
-  std::vector<int> ord(c->order2);
-  ord.insert(ord.end(), c->order1.begin(), c->order1.end());
-  HIPCHK(hipMemcpy(c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+  for (auto& v : c->cls) v.clear();
+  for (int b : idx) {
+    if (c->hN[b] == 0) continue;
+    c->cls[c->hN[b] <= 10 ? 0 : (c->hN[b] <= 21 ? 1 : 2)].push_back(b);
+  }
+  {
+    std::vector<int> ord(c->cls[2]);
+    ord.insert(ord.end(), c->cls[1].begin(), c->cls[1].end());
+    ord.insert(ord.end(), c->cls[0].begin(), c->cls[0].end());
+    ord.resize(batch, 0);
+    HIPCHK(hipMemcpy(c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+  }
   ENS(x, (size_t)batch * c->nmax * 8);
   ENS(work, (size_t)batch * 4 * c->nmax * 8);
   ENS(hist_s, (size_t)batch * m * c->nmax * 8);
@@ -545,31 +559,32 @@ topay_status topay_reset(topay_ctx* c) {
 
 }  // extern "C"
 
-template <typename KF1, typename KF2, typename... Args>
-static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, Args... args) {
-  // class 2 (11..21 pieces, two system rows per lane) first: the longest jobs
-  const int n2 = (int)c->order2.size(), n1 = (int)c->order1.size();
-  int launches = 0;
+template <typename KF1, typename KF2, typename KF3, typename... Args>
+static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args... args) {
+  // longest jobs first: class 3 (22..32 pieces), class 2 (11..21), class 1 (<= 10)
+  int launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
-  if (n2 > 0) {
+  for (int k = 2; k >= 0; k--) {
+    const std::vector<int>& v = c->cls[k];
+    const int nk = (int)v.size();
+    if (nk == 0) continue;
     int nm = 0;
-    for (int b : c->order2) nm = std::max(nm, c->hN[b]);
+    for (int b : v) nm = std::max(nm, c->hN[b]);
     DevBatch d = c->db;
+    d.order = c->db.order + off;
+    off += nk;
     const size_t lds = solve_lds_bytes(nm);
-    HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k2, dim3(n2), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
-    HIPCHK(hipGetLastError());
-    launches++;
-  }
-  if (n1 > 0) {
-    int nm = 0;
-    for (int b : c->order1) nm = std::max(nm, c->hN[b]);
-    DevBatch d = c->db;
-    d.order = c->db.order + n2;
-    const size_t lds = solve_lds_bytes(nm);
-    HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k1, dim3(n1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+    if (k == 2) {
+      HIPCHK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k3, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+    } else if (k == 1) {
+      HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k2, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+    } else {
+      HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k1, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+    }
     HIPCHK(hipGetLastError());
     launches++;
   }
@@ -583,7 +598,10 @@ topay_status topay_optimize(topay_ctx* c) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  topay_status s = launch_classes(c, k_solve1, k_solve2);
+  // candidates that were not launched keep success = 0 and cost = NaN
+  HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
+  topay_status s = launch_classes(c, k_solve1, k_solve2, k_solve3);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -623,6 +641,12 @@ topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, i
   if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   const int N = c->hN[i], rows = 6 * N;
+  if (N == 0) {  // not representable (more than TOPAY_MAX_N pieces): failed candidate, nothing else to report
+    if (success) *success = 0;
+    if (cost) *cost = 0.0 / 0.0;
+    if (n_pieces) *n_pieces = 0;
+    return TOPAY_OK;
+  }
   if (success) HIPCHK(hipMemcpy(success, c->success.as<int>() + i, 4, hipMemcpyDeviceToHost));
   if (cost) HIPCHK(hipMemcpy(cost, c->cost.as<double>() + i, 8, hipMemcpyDeviceToHost));
   if (n_pieces) *n_pieces = N;
@@ -644,6 +668,7 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->hN[i] == 0) { if (n) *n = 0; return TOPAY_ERR_TOO_MANY_PIECES; }
   const int nn = 10 * c->hN[i] - 8;
   if (n) *n = nn;
   if (x) {
@@ -660,6 +685,7 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   if (i < 0 || i >= c->B || (stage != 1 && stage != 2) || !x) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   const int N = c->hN[i], nn = 10 * N - 8;
+  if (N == 0) return TOPAY_ERR_TOO_MANY_PIECES;
   HIPCHK(hipMemcpy(c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
   double alm[4] = {alm_lambda ? alm_lambda[0] : c->hp.alm_init_lambda[0], alm_lambda ? alm_lambda[1] : c->hp.alm_init_lambda[1],
                    alm_rho ? alm_rho[0] : c->hp.alm_init_rho[0], alm_rho ? alm_rho[1] : c->hp.alm_init_rho[1]};
@@ -676,9 +702,12 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   if (N <= 10) {
     HIPCHK(hipFuncSetAttribute((const void*)k_eval1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_eval1, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
-  } else {
+  } else if (N <= 21) {
     HIPCHK(hipFuncSetAttribute((const void*)k_eval2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_eval2, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_eval3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_eval3, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -698,6 +727,7 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);
   HIPCHK(hipMemcpy(x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < c->B; b++) {
+    if (c->hN[b] == 0) continue;
     const int nn = 10 * c->hN[b] - 8;
     memcpy(&xs[(size_t)b * c->nmax], &x0[(size_t)b * (10 * TOPAY_MAX_N - 8)], (size_t)nn * 8);
     alm[4 * b] = c->hp.alm_init_lambda[0]; alm[4 * b + 1] = c->hp.alm_init_lambda[1];
@@ -706,7 +736,7 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   HIPCHK(hipMemcpy(c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  topay_status s = launch_classes(c, k_eval1, k_eval2, stage, repeats);
+  topay_status s = launch_classes(c, k_eval1, k_eval2, k_eval3, stage, repeats);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

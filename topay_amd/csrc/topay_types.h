@@ -6,7 +6,7 @@
 #define TOPAY_SP 25         // samples per piece = 2K+1
 #define TOPAY_EP 13         // even ("full") samples per piece = K+1
 #define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
-#define TOPAY_MAX_N 21      // 6N <= 128 rows = 2 rows per lane
+#define TOPAY_MAX_N 32      // 6N <= 192 rows = 3 system rows per lane (classes: N<=10 one row, <=21 two, <=32 three)
 #define TOPAY_WAVE 64
 
 // Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
