@@ -153,6 +153,8 @@ def main():
             "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
+            "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),
+            "p99_evals_per_traj": float(np.percentile(stats[:, 2] + stats[:, 5], 99)),
             "setup_seconds_untimed": setup_s,
         },
         "roofline": {

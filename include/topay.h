@@ -100,6 +100,10 @@ typedef struct {
   /* Deterministic replacement of the reference's 1.0 s wall-clock cap on the ALM loop
    * (moma_traj_opt.cpp:403-407): maximum number of outer iterations. */
   int alm_max_outer;
+  /* Second part of that replacement: the reference checks its 1.0 s clock only before starting another ALM round;
+   * here no further round is started once the stage-2 evaluations made so far reach this budget (default 1000,
+   * about one second of the reference's CPU path at ~1 ms per evaluation; 0 = unlimited). */
+  int alm_eval_budget;
   /* robot (MomaParam) */
   double chassis_height, chassis_colli_radius;
   double max_v, max_a, max_w, max_dw;

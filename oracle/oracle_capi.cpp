@@ -34,7 +34,7 @@ int orc_set_param(void* hh, const char* name, double v) {
   SETI(s1_normal_past) SETI(s1_shot_path_past) SETD(s1_shot_path_horizon)
   SETD(s2_time_weight) SETD(s2_moment_weight) SETD(s2_acc_weight) SETD(s2_domega_weight) SETD(s2_collision_weight)
   SETD(s2_mani_colli_weight) SETD(s2_self_colli_weight) SETD(s2_mani_pos_weight) SETD(s2_mani_vel_weight)
-  SETD(s2_mani_acc_weight) SETD(s2_mean_time_weight) SETD(alm_tolerance) SETI(alm_max_outer) SETI(exact_chain)
+  SETD(s2_mani_acc_weight) SETD(s2_mean_time_weight) SETD(alm_tolerance) SETI(alm_max_outer) SETI(alm_eval_budget) SETI(exact_chain)
 #undef SETD
 #undef SETI
   if (n == "s1_max_iterations") { p.s1_lbfgs.max_iterations = (int)v; return 0; }

@@ -43,6 +43,7 @@ class Params(C.Structure):
         ("s2_lbfgs", LbfgsParams),
         ("alm_init_lambda", C.c_double * 2), ("alm_init_rho", C.c_double * 2), ("alm_rho_max", C.c_double * 2),
         ("alm_gamma", C.c_double * 2), ("alm_tolerance", C.c_double), ("alm_max_outer", C.c_int),
+        ("alm_eval_budget", C.c_int),
         ("chassis_height", C.c_double), ("chassis_colli_radius", C.c_double),
         ("max_v", C.c_double), ("max_a", C.c_double), ("max_w", C.c_double), ("max_dw", C.c_double),
         ("colli_length", C.c_double * 8), ("colli_points", C.c_double * 16), ("colli_point_radius", C.c_double * 16),

@@ -251,6 +251,7 @@ static void make_dev_params(const topay_params_t& p, DevParams& d) {
   }
   d.alm_tolerance = p.alm_tolerance;
   d.alm_max_outer = p.alm_max_outer;
+  d.alm_eval_budget = p.alm_eval_budget;
   d.min_piece_num = p.min_piece_num;
   d.sample_interval = p.sample_interval;
   d.s1_normal_past = p.s1_normal_past; d.s1_shot_path_past = p.s1_shot_path_past;
@@ -325,6 +326,7 @@ topay_status topay_default_params(topay_params_t* p) {
   }
   p->alm_tolerance = 0.01;
   p->alm_max_outer = 30;
+  p->alm_eval_budget = 1000;
   // src/simulator/fake_moma/include/fake_moma/moma_param.h:36-126
   p->chassis_height = 0.155; p->chassis_colli_radius = 0.4;
   p->max_v = 1.0; p->max_a = 0.8; p->max_w = 1.25; p->max_dw = 1.0;

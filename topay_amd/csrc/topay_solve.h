@@ -326,7 +326,9 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         C.rho0 = fmin((1 + P.alm_gamma[0]) * C.rho0, P.alm_rho_max[0]);
         C.rho1 = fmin((1 + P.alm_gamma[1]) * C.rho1, P.alm_rho_max[1]);
       }
-      if (alm_iter >= P.alm_max_outer) break;  // deterministic stand-in for the 1.0 s cap (403-407)
+      // deterministic stand-in for the 1.0 s wall-clock cap checked at the top of the ALM loop (403-407)
+      if (alm_iter >= P.alm_max_outer) break;
+      if (P.alm_eval_budget > 0 && st_s2_ev >= P.alm_eval_budget) break;
       alm_iter++;
       evals = 0;
       mode = MODE_INIT;

@@ -52,7 +52,9 @@ struct DevParams {
   double alm_init_lambda[2], alm_init_rho[2], alm_rho_max[2], alm_gamma[2];
   double alm_tolerance;
   int alm_max_outer;
+  int alm_eval_budget;
   int min_piece_num;
+  int pad0_;
   double sample_interval;
   int s1_normal_past, s1_shot_path_past;
   double s1_shot_path_horizon;
