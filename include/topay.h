@@ -101,8 +101,8 @@ typedef struct {
    * (moma_traj_opt.cpp:403-407): maximum number of outer iterations. */
   int alm_max_outer;
   /* Second part of that replacement: the reference checks its 1.0 s clock only before starting another ALM round;
-   * here no further round is started once the stage-2 evaluations made so far reach this budget (default 1000,
-   * about one second of the reference's CPU path at ~1 ms per evaluation; 0 = unlimited). */
+   * here no further round is started once the stage-2 evaluations made so far reach this budget (default 2000,
+   * about one second of the reference's CPU path at ~0.5 ms per evaluation; 0 = unlimited). */
   int alm_eval_budget;
   /* robot (MomaParam) */
   double chassis_height, chassis_colli_radius;

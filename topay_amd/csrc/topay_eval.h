@@ -248,7 +248,7 @@ struct EvalCtx {
   lds_dp gdT;    // [N]        penalty dJ/dT accumulator
   lds_dp pcs;    // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
   lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
-  lds_dp X;      // union region: band+rdiag+adjoint (23*rows) | sample buffers (26N + 1024)
+  lds_dp X;      // union region: band + reciprocal diagonal (14*rows) | sample buffers (26N + 960)
   // global
   glb_cdp x;
   glb_dp g;
@@ -264,8 +264,8 @@ struct EvalCtx {
 
 __host__ __device__ __forceinline__ int lds_doubles(int Nmax) {
   const int rows = 6 * Nmax;
-  int xr = 23 * rows;
-  int sr = 26 * Nmax + 1024;
+  int xr = 14 * rows;
+  int sr = 26 * Nmax + 960;
   return 18 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + (xr > sr ? xr : sr);
 }
 __device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
@@ -820,7 +820,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   lds_dp gC = C.gC;
 
   lds_dp gxy = C.X;                  // [13N][2] positional gradient of each even sample
-  lds_dp pbuf = C.X + 26 * N;        // [16][64] pass buffer (also the per-lane stash around the manipulator block)
+  lds_dp pbuf = C.X + 26 * N;        // [15][64] pass buffer (also the per-lane stash around the manipulator block)
   const int NE = TOPAY_EP * N;       // even samples
   const int npass = (NE + 63) / 64;
   double cost_pen = 0.0;             // per-lane partial penalty cost
@@ -1221,7 +1221,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
   lds_dp band = C.X;
   lds_dp rdiag = C.X + 13 * rows;
-  lds_dp adj = C.X + 14 * rows;  // [9][rows]
+  lds_dp adj = C.gC;             // [9][rows]: the adjoint solve runs in place on the dJ/dC accumulator
   for (int t = lane; t < 14 * rows; t += 64) C.X[t] = C.lu[t];
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {

@@ -214,7 +214,13 @@ struct topay_ctx {
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
   // batch
   int B = 0, Nmax = 0, nmax = 0, total_states = 0, Pmax = 0;
-  std::vector<int> hN, cls[3];  // per-trajectory N (0 = not representable, skipped); launch order of each row class
+  // per-trajectory N (0 = not representable, skipped); launch buckets by N (LDS is sized per bucket)
+  std::vector<int> hN;
+  static constexpr int NBUCKET = 7;
+  std::vector<int> cls[NBUCKET];
+  hipStream_t bstream[NBUCKET] = {nullptr};
+  hipEvent_t bevent[NBUCKET] = {nullptr};
+  hipEvent_t bstart = nullptr;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
@@ -326,7 +332,7 @@ topay_status topay_default_params(topay_params_t* p) {
   }
   p->alm_tolerance = 0.01;
   p->alm_max_outer = 30;
-  p->alm_eval_budget = 1000;
+  p->alm_eval_budget = 2000;
   // src/simulator/fake_moma/include/fake_moma/moma_param.h:36-126
   p->chassis_height = 0.155; p->chassis_colli_radius = 0.4;
   p->max_v = 1.0; p->max_a = 0.8; p->max_w = 1.25; p->max_dw = 1.0;
@@ -371,6 +377,11 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   HIPCHK(hipStreamCreate(&c->stream2));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
+  HIPCHK(hipEventCreate(&c->bstart));
+  for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+    HIPCHK(hipStreamCreate(&c->bstream[k]));
+    HIPCHK(hipEventCreate(&c->bevent[k]));
+  }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
   *out = c;
@@ -386,6 +397,11 @@ void topay_destroy(topay_ctx* c) {
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
+  for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+    if (c->bstream[k]) (void)hipStreamDestroy(c->bstream[k]);
+    if (c->bevent[k]) (void)hipEventDestroy(c->bevent[k]);
+  }
+  if (c->bstart) (void)hipEventDestroy(c->bstart);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -417,6 +433,13 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   return TOPAY_OK;
 }
 
+// launch buckets by number of pieces: upper bounds (inclusive); rows per lane = 1 / 1 / 2 / 2 / 2 / 3 / 3
+static const int kBucketMaxN[topay_ctx::NBUCKET] = {7, 10, 13, 16, 21, 26, 32};
+static int bucket_of(int N) {
+  for (int k = 0; k < topay_ctx::NBUCKET; k++)
+    if (N <= kBucketMaxN[k]) return k;
+  return topay_ctx::NBUCKET - 1;
+}
 static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8) * sizeof(double); }
 
 static topay_status push_params(topay_ctx* c) {
@@ -512,12 +535,11 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   for (auto& v : c->cls) v.clear();
   for (int b : idx) {
     if (c->hN[b] == 0) continue;
-    c->cls[c->hN[b] <= 10 ? 0 : (c->hN[b] <= 21 ? 1 : 2)].push_back(b);
+    c->cls[bucket_of(c->hN[b])].push_back(b);
   }
   {
-    std::vector<int> ord(c->cls[2]);
-    ord.insert(ord.end(), c->cls[1].begin(), c->cls[1].end());
-    ord.insert(ord.end(), c->cls[0].begin(), c->cls[0].end());
+    std::vector<int> ord;
+    for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) ord.insert(ord.end(), c->cls[k].begin(), c->cls[k].end());
     ord.resize(batch, 0);
     HIPCHK(hipMemcpy(c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
   }
@@ -563,11 +585,14 @@ topay_status topay_reset(topay_ctx* c) {
 
 template <typename KF1, typename KF2, typename KF3, typename... Args>
 static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args... args) {
-  // longest jobs first: class 3 (22..32 pieces), class 2 (11..21), class 1 (<= 10)
+  // One launch per N-bucket, each on its own stream so that the tail of one bucket overlaps the others.
+  // Longest jobs first.  The context's main stream waits for all of them (events), so the caller's
+  // ev0/ev1 pair on the main stream brackets the whole solve.
   int launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
-  for (int k = 2; k >= 0; k--) {
+  HIPCHK(hipEventRecord(c->bstart, c->stream));  // params + resets on the main stream come first
+  for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
     const std::vector<int>& v = c->cls[k];
     const int nk = (int)v.size();
     if (nk == 0) continue;
@@ -577,19 +602,24 @@ static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args...
     d.order = c->db.order + off;
     off += nk;
     const size_t lds = solve_lds_bytes(nm);
-    if (k == 2) {
+    hipStream_t st = c->bstream[k];
+    HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
+    if (nm > 21) {
       HIPCHK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k3, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
-    } else if (k == 1) {
+      hipLaunchKernelGGL(k3, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+    } else if (nm > 10) {
       HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k2, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+      hipLaunchKernelGGL(k2, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     } else {
       HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k1, dim3(nk), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, args..., nm);
+      hipLaunchKernelGGL(k1, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->bevent[k], st));
     launches++;
   }
+  for (int k = 0; k < topay_ctx::NBUCKET; k++)
+    if (!c->cls[k].empty()) HIPCHK(hipStreamWaitEvent(c->stream, c->bevent[k], 0));
   c->last_launches = launches;
   return TOPAY_OK;
 }

@@ -693,6 +693,12 @@ struct World {
     Cell cs = toCell(start[0], start[1]), cg = toCell(goal[0], goal[1]);
     int made = 0;
     double dsg = std::hypot(start[0] - goal[0], start[1] - goal[1]);
+    auto cells_len = [&](const std::vector<Cell>& cs_) {
+      double L = 0.0;
+      for (size_t i = 1; i < cs_.size(); i++) L += std::hypot((double)(cs_[i].x - cs_[i - 1].x), (double)(cs_[i].y - cs_[i - 1].y));
+      return L * gm.resolution;
+    };
+    double min_len = -1.0;  // length of the shortest (direct) candidate
     for (int c = 0; c < n_cand; c++) {
       std::vector<Cell> cells;
       bool ok = false, via = false;
@@ -718,6 +724,9 @@ struct World {
           shortcut(gm, b, thr, sb);
           cells = sa;
           cells.insert(cells.end(), sb.begin() + 1, sb.end());
+          // TopologyPRM::selectShortPaths keeps a candidate only if it is shorter than ratio_to_short (2.0) times the
+          // shortest one (topo_prm.cpp:384-407, params/topo_prm.yaml:17)
+          if (min_len > 0.0 && cells_len(cells) >= 2.0 * min_len) continue;
           via = true;
           ok = true;
         }
@@ -730,6 +739,7 @@ struct World {
       std::vector<Cell> sc;
       if (via) sc = cells;
       else shortcut(gm, cells, thr, sc);
+      if (c == 0) min_len = cells_len(sc);
       std::vector<std::array<double, 2>> raw;
       raw.push_back({start[0], start[1]});
       for (size_t i = 1; i + 1 < sc.size(); i++) raw.push_back(cellCenter(sc[i]));
