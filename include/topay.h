@@ -101,9 +101,10 @@ typedef struct {
    * (moma_traj_opt.cpp:403-407): maximum number of outer iterations. */
   int alm_max_outer;
   /* Second part of that replacement: the reference checks its 1.0 s clock only before starting another ALM round;
-   * here no further round is started once the stage-2 evaluations made so far reach this budget (default 2000,
-   * about one second of the reference's CPU path at ~0.5 ms per evaluation; 0 = unlimited). */
-  int alm_eval_budget;
+   * here no further round is started once the stage-2 work done so far -- evaluations x pieces, the unit the
+   * cost of an evaluation is proportional to -- reaches this budget.  Default 24000 piece-evaluations: one second
+   * of the CPU path at the ~42 us per piece-evaluation measured for the oracle.  0 = unlimited. */
+  int alm_work_budget;
   /* robot (MomaParam) */
   double chassis_height, chassis_colli_radius;
   double max_v, max_a, max_w, max_dw;
@@ -177,6 +178,11 @@ topay_status topay_get_result(topay_ctx* ctx, int i, int* success, double* cost,
  * {stage1_ret, stage1_iters, stage1_evals, stage2_last_ret, stage2_iters, stage2_evals, alm_outer, sum_bound}
  * sum_bound = sum over stage-2 iterations of the two-loop history length (roofline accounting). */
 topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
+
+/* Per-candidate optimisation time in microseconds, measured on the device (the reference logs the same quantity per
+ * candidate, planner.cpp:893-905 "optimization time").  start_us (optional): when each solve started, on the same
+ * device clock (only differences are meaningful).  Either pointer may be NULL. */
+topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
 
 /* Number of decision variables of candidate i (n = 10N - 8) and the packed vector
  * x = [tau(N) | theta(N-1) | s(N) | Vq(7 x (N-1), column = knot)] (moma_traj_opt.cpp:324-344). */

@@ -201,3 +201,31 @@ def optimize_batch(m, path_len, paths, bvel=None, bacc=None, nthreads=1, alm_max
     if maxN > 0:
         out.update(durations=dur.reshape(B, maxN), coeffs=coef.reshape(B, maxN, 9, 6), knots=knots.reshape(B, maxN + 1, 2))
     return out
+
+
+def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1):
+    """Thread-pool batch solve where trajectory b runs against maps[map_id[b]] (cpu_baseline leg of bench.py)."""
+    L = lib()
+    M = len(maps)
+    origin = np.ascontiguousarray(np.stack([m.origin for m in maps]), dtype=np.float64)
+    res = np.ascontiguousarray([m.res for m in maps], dtype=np.float64)
+    dims = np.ascontiguousarray(np.stack([m.dims for m in maps]), dtype=np.int32)
+    mn = np.ascontiguousarray(np.stack([m.min_b for m in maps]), dtype=np.float64)
+    mx = np.ascontiguousarray(np.stack([m.max_b for m in maps]), dtype=np.float64)
+    P = C.POINTER(C.c_double)
+    e2 = (P * M)(*[_dp(m.esdf2d) for m in maps])
+    e3 = (P * M)(*[_dp(m.esdf3d) for m in maps])
+    map_id = np.ascontiguousarray(map_id, dtype=np.int32)
+    path_len = np.ascontiguousarray(path_len, dtype=np.int32)
+    paths = np.ascontiguousarray(paths, dtype=np.float64)
+    B = len(path_len)
+    success = np.zeros(B, dtype=np.int32)
+    cost = np.zeros(B)
+    npc = np.zeros(B, dtype=np.int32)
+    stats = np.zeros(B * 8, dtype=np.int32)
+    each = np.zeros(B)
+    L.orc_optimize_batch_maps.restype = C.c_double
+    secs = L.orc_optimize_batch_maps(M, _dp(origin), _dp(res), _ip(dims), _dp(mn), _dp(mx), e2, e3, _ip(map_id), B,
+                                     _ip(path_len), _dp(paths), nthreads, _ip(success), _dp(cost), _ip(npc), _ip(stats),
+                                     _dp(each))
+    return dict(success=success, cost=cost, n_pieces=npc, stats=stats.reshape(B, 8), seconds=secs, seconds_each=each)

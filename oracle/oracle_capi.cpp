@@ -34,7 +34,7 @@ int orc_set_param(void* hh, const char* name, double v) {
   SETI(s1_normal_past) SETI(s1_shot_path_past) SETD(s1_shot_path_horizon)
   SETD(s2_time_weight) SETD(s2_moment_weight) SETD(s2_acc_weight) SETD(s2_domega_weight) SETD(s2_collision_weight)
   SETD(s2_mani_colli_weight) SETD(s2_self_colli_weight) SETD(s2_mani_pos_weight) SETD(s2_mani_vel_weight)
-  SETD(s2_mani_acc_weight) SETD(s2_mean_time_weight) SETD(alm_tolerance) SETI(alm_max_outer) SETI(alm_eval_budget) SETI(exact_chain)
+  SETD(s2_mani_acc_weight) SETD(s2_mean_time_weight) SETD(alm_tolerance) SETI(alm_max_outer) SETI(alm_work_budget) SETI(exact_chain)
 #undef SETD
 #undef SETI
   if (n == "s1_max_iterations") { p.s1_lbfgs.max_iterations = (int)v; return 0; }
@@ -177,6 +177,47 @@ double orc_optimize_batch(const double origin[3], double res, const int dims[3],
       s[4] = st.stage2_iters; s[5] = st.stage2_evals; s[6] = st.alm_outer; s[7] = st.sum_bound;
       if (durations && h.opt.piece_num <= maxN)
         h.opt.getTraj(durations + (size_t)b * maxN, coeffs + (size_t)b * maxN * 54, knots + (size_t)b * (maxN + 1) * 2);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < std::max(1, nthreads); t++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Same, but every trajectory names its own map (benchmark_tables batch: one map per scenario).  One pool of
+// nthreads workers over all trajectories.  Map descriptors are arrays of length n_maps.
+double orc_optimize_batch_maps(int n_maps, const double* origin /*[M][3]*/, const double* res /*[M]*/,
+                               const int* dims /*[M][3]*/, const double* min_b, const double* max_b,
+                               const double* const* esdf2d, const double* const* esdf3d, const int* map_id, int batch,
+                               const int* path_len, const double* paths, int nthreads, int* success, double* cost,
+                               int* n_pieces, int* stats, double* seconds_each) {
+  std::vector<size_t> offs(batch + 1, 0);
+  for (int b = 0; b < batch; b++) offs[b + 1] = offs[b] + (size_t)path_len[b] * 10;
+  std::vector<double> zeros(20, 0.0);
+  std::atomic<int> next(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto worker = [&]() {
+    OracleHandle h;
+    h.opt.map = &h.map;
+    while (true) {
+      int b = next.fetch_add(1);
+      if (b >= batch) break;
+      const int m = map_id[b];
+      if (m < 0 || m >= n_maps) { success[b] = 0; continue; }
+      h.map.set(origin + 3 * m, res[m], dims + 3 * m, esdf2d[m], esdf3d[m]);
+      h.map.setBounds(min_b + 3 * m, max_b + 3 * m);
+      auto t1 = std::chrono::steady_clock::now();
+      h.opt.setInitTraj(paths + offs[b], path_len[b], zeros.data(), zeros.data());
+      bool ok = h.opt.optimize();
+      if (seconds_each) seconds_each[b] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+      success[b] = ok ? 1 : 0;
+      cost[b] = h.opt.traj_cost;
+      n_pieces[b] = h.opt.piece_num;
+      const SolveStats& st = h.opt.stats;
+      int* s = stats + (size_t)b * 8;
+      s[0] = st.stage1_ret; s[1] = st.stage1_iters; s[2] = st.stage1_evals; s[3] = st.stage2_last_ret;
+      s[4] = st.stage2_iters; s[5] = st.stage2_evals; s[6] = st.alm_outer; s[7] = st.sum_bound;
     }
   };
   std::vector<std::thread> th;

@@ -219,6 +219,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 inline void __builtin_amdgcn_wave_barrier() { hip_emu::barrier(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+inline unsigned long long wall_clock64() { return 0; }
 inline unsigned long long __builtin_amdgcn_s_memtime() { return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count(); }
 inline int __double2loint(double v) { long long b; memcpy(&b, &v, 8); return (int)(b & 0xffffffffLL); }
 inline int __double2hiint(double v) { long long b; memcpy(&b, &v, 8); return (int)((b >> 32) & 0xffffffffLL); }
@@ -260,6 +261,8 @@ inline hipError_t hipMemcpyToSymbolAsync(void* sym, const void* src, size_t n, s
   return 0;
 }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+#define hipStreamNonBlocking 1
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu(); return 0; }

@@ -43,7 +43,7 @@ class Params(C.Structure):
         ("s2_lbfgs", LbfgsParams),
         ("alm_init_lambda", C.c_double * 2), ("alm_init_rho", C.c_double * 2), ("alm_rho_max", C.c_double * 2),
         ("alm_gamma", C.c_double * 2), ("alm_tolerance", C.c_double), ("alm_max_outer", C.c_int),
-        ("alm_eval_budget", C.c_int),
+        ("alm_work_budget", C.c_int),
         ("chassis_height", C.c_double), ("chassis_colli_radius", C.c_double),
         ("max_v", C.c_double), ("max_a", C.c_double), ("max_w", C.c_double), ("max_dw", C.c_double),
         ("colli_length", C.c_double * 8), ("colli_points", C.c_double * 16), ("colli_point_radius", C.c_double * 16),
@@ -85,6 +85,7 @@ def load(path=None):
     L.topay_get_batch.argtypes = [C.c_void_p, c_ip, c_dp, c_ip]
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
+    L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp]
     L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
@@ -207,6 +208,17 @@ class MomaTrajOptBatch:
         s = np.zeros(self.batch * 8, dtype=np.int32)
         _chk(self.L, self.L.topay_get_stats(self.h, _ip(s)))
         return s.reshape(self.batch, 8)
+
+    def elapsed_us(self):
+        """Device-measured optimisation time of every candidate (microseconds)."""
+        t = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_get_elapsed_us(self.h, _dp(t), None))
+        return t
+
+    def start_us(self):
+        t = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_get_elapsed_us(self.h, None, _dp(t)))
+        return t - t.min()
 
     def get_x(self, i):
         n = C.c_int(0)

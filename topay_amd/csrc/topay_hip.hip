@@ -91,6 +91,7 @@ template <int RMAX>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds,
                                            int init_stride_N) {
   const int b = Bt.order[blockIdx.x];
+  const unsigned long long t_begin = wall_clock64();
   EvalCtx C;
   load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
@@ -132,6 +133,8 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     Bt.xyerr[2 * b] = C.fxe0;
     Bt.xyerr[2 * b + 1] = C.fxe1;
     Bt.alm[4 * b] = C.lam0; Bt.alm[4 * b + 1] = C.lam1; Bt.alm[4 * b + 2] = C.rho0; Bt.alm[4 * b + 3] = C.rho1;
+    Bt.elapsed_us[b] = (double)(wall_clock64() - t_begin) * 0.01;
+    Bt.start_us[b] = (double)t_begin * 0.01;
   }
 }
 
@@ -201,6 +204,14 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
+#define TOPAY_NBUCKET 7
+// launch buckets by number of pieces: upper bounds (inclusive); rows per lane = 1 / 1 / 2 / 2 / 2 / 3 / 3.
+// Each bucket has its own stream.  HIP maps streams of one priority onto a pool of 4 hardware queues shared with
+// every other stream of the process, and streams that share a queue serialise (measured: tools/queue_probe.hip),
+// so the buckets are spread over the three priority levels -- at most three per level (the normal level also carries the context's own two streams and the null stream) -- with the longest
+// trajectories on the highest priority: their workgroups are dispatched first, which is what the tail needs.
+static const int kBucketMaxN[TOPAY_NBUCKET] = {7, 10, 13, 16, 21, 26, 32};
+static const int kBucketPrio[TOPAY_NBUCKET] = {+1, +1, +1, 0, -1, -1, -1};  // -1 greatest ... +1 least
 struct topay_ctx {
   int device = 0;
   topay_params_t hp;
@@ -216,7 +227,7 @@ struct topay_ctx {
   int B = 0, Nmax = 0, nmax = 0, total_states = 0, Pmax = 0;
   // per-trajectory N (0 = not representable, skipped); launch buckets by N (LDS is sized per bucket)
   std::vector<int> hN;
-  static constexpr int NBUCKET = 7;
+  static constexpr int NBUCKET = TOPAY_NBUCKET;
   std::vector<int> cls[NBUCKET];
   hipStream_t bstream[NBUCKET] = {nullptr};
   hipEvent_t bevent[NBUCKET] = {nullptr};
@@ -224,7 +235,7 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus;
   int trace_cap = 0;
   DevBatch db;
   bool have_traj = false, solved = false;
@@ -257,7 +268,7 @@ static void make_dev_params(const topay_params_t& p, DevParams& d) {
   }
   d.alm_tolerance = p.alm_tolerance;
   d.alm_max_outer = p.alm_max_outer;
-  d.alm_eval_budget = p.alm_eval_budget;
+  d.alm_work_budget = p.alm_work_budget;
   d.min_piece_num = p.min_piece_num;
   d.sample_interval = p.sample_interval;
   d.s1_normal_past = p.s1_normal_past; d.s1_shot_path_past = p.s1_shot_path_past;
@@ -332,7 +343,7 @@ topay_status topay_default_params(topay_params_t* p) {
   }
   p->alm_tolerance = 0.01;
   p->alm_max_outer = 30;
-  p->alm_eval_budget = 2000;
+  p->alm_work_budget = 24000;
   // src/simulator/fake_moma/include/fake_moma/moma_param.h:36-126
   p->chassis_height = 0.155; p->chassis_colli_radius = 0.4;
   p->max_v = 1.0; p->max_a = 0.8; p->max_w = 1.25; p->max_dw = 1.0;
@@ -379,7 +390,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   HIPCHK(hipEventCreate(&c->ev1));
   HIPCHK(hipEventCreate(&c->bstart));
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    HIPCHK(hipStreamCreate(&c->bstream[k]));
+    HIPCHK(hipStreamCreateWithPriority(&c->bstream[k], hipStreamNonBlocking, kBucketPrio[k]));
     HIPCHK(hipEventCreate(&c->bevent[k]));
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
@@ -394,7 +405,7 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace};
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
@@ -433,8 +444,6 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   return TOPAY_OK;
 }
 
-// launch buckets by number of pieces: upper bounds (inclusive); rows per lane = 1 / 1 / 2 / 2 / 2 / 3 / 3
-static const int kBucketMaxN[topay_ctx::NBUCKET] = {7, 10, 13, 16, 21, 26, 32};
 static int bucket_of(int N) {
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
     if (N <= kBucketMaxN[k]) return k;
@@ -559,6 +568,8 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(knots, (size_t)batch * 2 * (Nmax + 1) * 8);
   ENS(alm, (size_t)batch * 4 * 8);
   ENS(fout, (size_t)batch * 8);
+  ENS(elapsed, (size_t)batch * 8);
+  ENS(startus, (size_t)batch * 8);
 #undef ENS
   d.Nmax = Nmax; d.nmax = c->nmax; d.hist_m = m;
   d.x = c->x.as<double>(); d.work = c->work.as<double>();
@@ -568,6 +579,9 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.success = c->success.as<int>(); d.cost = c->cost.as<double>(); d.stats = c->stats.as<int>();
   d.xyerr = c->xyerr.as<double>(); d.coef = c->coef.as<double>(); d.T = c->T.as<double>();
   d.knots = c->knots.as<double>(); d.alm = c->alm.as<double>(); d.fout = c->fout.as<double>();
+  d.elapsed_us = c->elapsed.as<double>();
+  d.start_us = c->startus.as<double>();
+  HIPCHK(hipMemset(c->elapsed.p, 0, (size_t)batch * 8));
   HIPCHK(hipMemset(c->success.p, 0, (size_t)batch * 4));
   HIPCHK(hipMemset(c->stats.p, 0, (size_t)batch * 32));
   c->have_traj = true;
@@ -657,6 +671,14 @@ topay_status topay_get_batch(topay_ctx* c, int* success, double* cost, int* n_pi
   if (success) HIPCHK(hipMemcpy(success, c->success.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
   if (cost) HIPCHK(hipMemcpy(cost, c->cost.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   if (n_pieces) memcpy(n_pieces, c->hN.data(), (size_t)c->B * 4);
+  return TOPAY_OK;
+}
+
+topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  if (us) HIPCHK(hipMemcpy(us, c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (start_us) HIPCHK(hipMemcpy(start_us, c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 

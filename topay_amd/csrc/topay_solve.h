@@ -328,7 +328,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       }
       // deterministic stand-in for the 1.0 s wall-clock cap checked at the top of the ALM loop (403-407)
       if (alm_iter >= P.alm_max_outer) break;
-      if (P.alm_eval_budget > 0 && st_s2_ev >= P.alm_eval_budget) break;
+      if (P.alm_work_budget > 0 && st_s2_ev * C.N >= P.alm_work_budget) break;
       alm_iter++;
       evals = 0;
       mode = MODE_INIT;

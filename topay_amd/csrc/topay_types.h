@@ -52,7 +52,7 @@ struct DevParams {
   double alm_init_lambda[2], alm_init_rho[2], alm_rho_max[2], alm_gamma[2];
   double alm_tolerance;
   int alm_max_outer;
-  int alm_eval_budget;
+  int alm_work_budget;
   int min_piece_num;
   int pad0_;
   double sample_interval;
@@ -103,6 +103,8 @@ struct DevBatch {
   double* knots;      // [B][(Nmax+1)*2]
   double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
   double* fout;       // [B] eval hook output
+  double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
+  double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
   const int* order;   // [B] block -> trajectory map
   double* trace;      // optional [B][trace_cap] f of every evaluation (debug / parity tooling), may be null
   int trace_cap;
