@@ -6,7 +6,7 @@ from topay_amd import api
 from topay_amd.harness import workload as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 tb = wl.TablesBatch(S, 8, base_seed=42, nthreads=0)
-opt = api.MomaTrajOptBatch(device=0)
+opt = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB"))
 slot = {}
 for k, s in enumerate(tb.scenarios):
     w = tb.world(s)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun): kernel trace + stats of the bench command, then separate PMC passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass), then the counter calibration.  Outputs under gpurun_out/prof_$1.
+R=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/bench_kt.json 2> $OUT/kt.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- $ROOT/tools/pmc_calib > $OUT/calib.txt 2> $OUT/cal_fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- $ROOT/tools/pmc_calib >> $OUT/calib.txt 2> $OUT/cal_write.log
+python3 $ROOT/bench.py $ARGS > $OUT/bench_plain.json 2>/dev/null
+find $OUT -name "*.csv" | head -50
+# keep the merge-back small: kernel trace CSVs of the bench can be large
+find $OUT -name "*.csv" -size +20M -exec gzip {} \;
+du -sh $OUT

@@ -12,9 +12,13 @@
 
 #include "topay_solve.h"
 
-// minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane)
+// Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
+// One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
+// two VGPRs per value), so a 256-register budget only moves that state into scratch -- measured 1.5-3x slower per
+// evaluation (offload-LTO builds that enforce 256 / 168 registers in the callees), while the 512-register build has
+// no VGPR spills in the evaluation and is the fastest variant ("Occupancy").
 #ifndef TOPAY_WAVES_PER_EU
-#define TOPAY_WAVES_PER_EU 2
+#define TOPAY_WAVES_PER_EU 1
 #endif
 
 using namespace topay;
