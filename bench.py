@@ -145,6 +145,20 @@ def main():
     abytes = algorithmic_bytes(stats, n_pieces)
     kms = float(np.mean(kernel_ms))
     achieved = abytes / (kms * 1e-3) / 1e9
+    # HBM-side bytes of one step from the committed PMC passes of this same command (tools/profile_round.sh; FETCH_SIZE
+    # and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected live here).  Only quoted when the
+    # workload is the one that was profiled.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if cands and S == 1024 and Ccand == 8:
+            tj = json.load(open(cands[-1]))
+            traffic = float(tj["traffic_bytes"])
+            traffic_src = os.path.relpath(cands[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "trajectories/sec to L-BFGS convergence (benchmark_tables batch)",
         "value": total_traj * args.steps / elapsed,
@@ -173,8 +187,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": "k_solve1/k_solve2 (persistent per-trajectory solve)", "kernel_ms": kms,
+            "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+            "kernel": "k_solve1/2/3 (persistent per-trajectory solve, one concurrent launch per N-bucket)",
+            "kernel_ms": kms,
             "algorithmic_bytes_per_step": abytes,
         },
     }
