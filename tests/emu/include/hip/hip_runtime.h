@@ -222,6 +222,7 @@ inline void __builtin_amdgcn_wave_barrier() { hip_emu::barrier(); }
 inline unsigned long long wall_clock64() { return 0; }
 inline unsigned long long __builtin_amdgcn_s_memtime() { return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count(); }
 inline int __double2loint(double v) { long long b; memcpy(&b, &v, 8); return (int)(b & 0xffffffffLL); }
+inline double __longlong_as_double(long long b) { double v; memcpy(&v, &b, 8); return v; }
 inline int __double2hiint(double v) { long long b; memcpy(&b, &v, 8); return (int)((b >> 32) & 0xffffffffLL); }
 inline double __hiloint2double(int hi, int lo) {
   unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;

@@ -3,8 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from topay_amd.harness import workload as wl
 from topay_amd import api
-gpu = api.MomaTrajOptBatch(device=0, lib_path="topay_amd/lib/libtopay_hip_stamps.so")
-names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "-", "(body)", "(mani)"]
+gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB", "topay_amd/lib/libtopay_hip_stamps.so"))
+names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(gen sweeps)", "(body)", "(mani)", "(adj sweeps)", "-"]
 for S in (128,):
     w2, lens2, paths2, scen2 = wl.cuboids_batch(S, 8)
     gpu.set_map(w2.origin, w2.res, w2.dims, w2.min_b, w2.max_b, w2.esdf2d, w2.esdf3d)
@@ -14,13 +14,22 @@ for S in (128,):
     t = time.time(); ok = gpu.optimize(); ms, nl = gpu.last_kernel_ms()
     st = gpu.stats()
     ev = (st[:, 2] + st[:, 5]).astype(float)
-    tot = np.zeros(14)
+    tot = np.zeros(16)
     for b in range(B):
         raw = gpu.get_trace(b)
-        tk = raw[8:8 + 16].view(np.int64)[:14].astype(float)
+        tk = raw[8:8 + 16].view(np.int64)[:16].astype(float)
         tot += tk
     print("B", B, "kernel %.1f ms; evals %d" % (ms, ev.sum()))
     cyc_per_eval = tot / ev.sum()
     for n, c in zip(names, cyc_per_eval):
         print("   %-9s %10.0f cycles/eval" % (n, c))
     print("   total %.0f cycles/eval" % cyc_per_eval[:10].sum(), " N mean", gpu.n_pieces().mean(), "mean bound per iter", st[:, 7].sum() / max(1, st[:, 4].sum()))
+
+import ctypes as C
+try:
+    arr = (C.c_longlong * 8)()
+    gpu.L.topay_debug_mani_stamps(arr)
+    v = np.array(list(arr), dtype=float)
+    print("manipulator phases (share):", dict(zip(["sincos", "walk1", "pairs", "esdf", "walks2", "limits"], np.round(v[:6] / v[:6].sum(), 3))))
+except Exception as e:
+    print("no mani stamps", e)

@@ -17,6 +17,7 @@
 // (moma_traj_opt.cpp:1313-1314,1667-1668,1812-1822) is the matching suffix scan, done in a second
 // sweep.  Per-sample gradient rows travel sample-lane -> row-lane through a small LDS pass buffer.
 #pragma once
+
 #include <hip/hip_runtime.h>
 
 #include "topay_math.h"
@@ -29,6 +30,14 @@
 // Optimizer/robot parameters live in constant memory: every access is a scalar load the compiler can re-issue at
 // the point of use instead of keeping hundreds of SGPRs of kernel arguments alive across the whole solve.
 __constant__ DevParams g_P;
+
+// Scheduling fences between the independent sub-blocks of the manipulator block (they bounded register pressure
+// when the kernels were built for 256 registers; with the 512-register budget the scheduler is left free).
+#ifdef TOPAY_USE_SCHED_FENCE
+#define TOPAY_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TOPAY_SCHED_FENCE() do { } while (0)
+#endif
 
 namespace topay {
 
@@ -143,6 +152,14 @@ __device__ __forceinline__ void smoothL1(double x, double mu, double& f, double&
 // ESDF interpolation — grid_map.h:364-441 (2-D), 443-509 (3-D); out of map => d = 0, grad = 0
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+// Clamped cell index pair (i, i+1) -> (lo, hi) as grid_map.h:727-733 does, without ever forming i + 1 on an
+// unclamped i: a saturated float->int conversion (points far outside the map) would overflow, and the compiler
+// may assume it does not.
+__device__ __forceinline__ void clamp_pair(int i, int top, int& lo, int& hi) {
+  const int ic = i < -1 ? -1 : (i > top ? top : i);
+  lo = ic < 0 ? 0 : ic;
+  hi = ic + 1 > top ? top : ic + 1;
+}
 
 // Wave-uniform copy of a map descriptor, forced into scalar registers.
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -181,8 +198,9 @@ __device__ __forceinline__ void esdf2d_query(const DevMap& M, double px, double 
     double dx = (px - ((ix + 0.5) * r + M.origin[0])) * ri;
     double dy = (py - ((iy + 0.5) * r + M.origin[1])) * ri;
     const int ny = M.dims[1];
-    int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
-    int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
+    int x0, x1, y0, y1;
+    clamp_pair(ix, M.dims[0] - 1, x0, x1);
+    clamp_pair(iy, ny - 1, y0, y1);
     glb_cdp e = M.esdf2d;
     double v00 = e[(size_t)x0 * ny + y0], v01 = e[(size_t)x0 * ny + y1];
     double v10 = e[(size_t)x1 * ny + y0], v11 = e[(size_t)x1 * ny + y1];
@@ -200,8 +218,9 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
                                              double& gy, double& gz) {
   bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || pz < M.min_b[2] + 1e-4 ||
               px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4 || pz > M.max_b[2] - 1e-4);
-  dist = 0.0; gx = 0.0; gy = 0.0; gz = 0.0;
-  if (in) {
+  // branch-free: the gathers are issued unconditionally at clamped indices (so that the scheduler can start them
+  // early and overlap several spheres) and the result is discarded for points outside the map (d = 0, grad = 0)
+  {
     const double r = M.res, ri = M.res_inv;
     int ix = (int)floor((px - 0.5 * r - M.origin[0]) * ri);
     int iy = (int)floor((py - 0.5 * r - M.origin[1]) * ri);
@@ -210,9 +229,10 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
     double dy = (py - ((iy + 0.5) * r + M.origin[1])) * ri;
     double dz = (pz - ((iz + 0.5) * r + M.origin[2])) * ri;
     const int ny = M.dims[1], nz = M.dims[2];
-    int x0 = clampi(ix, M.dims[0] - 1), x1 = clampi(ix + 1, M.dims[0] - 1);
-    int y0 = clampi(iy, ny - 1), y1 = clampi(iy + 1, ny - 1);
-    int z0 = clampi(iz, nz - 1), z1 = clampi(iz + 1, nz - 1);
+    int x0, x1, y0, y1, z0, z1;
+    clamp_pair(ix, M.dims[0] - 1, x0, x1);
+    clamp_pair(iy, ny - 1, y0, y1);
+    clamp_pair(iz, nz - 1, z0, z1);
     glb_cdp e = M.esdf3d;
     size_t b00 = ((size_t)x0 * ny + y0) * nz, b01 = ((size_t)x0 * ny + y1) * nz;
     size_t b10 = ((size_t)x1 * ny + y0) * nz, b11 = ((size_t)x1 * ny + y1) * nz;
@@ -234,6 +254,7 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
     g0 = fma(dz * dy, v111 - v011, g0);
     gx = g0 * ri;
   }
+  dist = in ? dist : 0.0; gx = in ? gx : 0.0; gy = in ? gy : 0.0; gz = in ? gz : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +324,74 @@ __device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
 #define SUBSTAMP_BEGIN(C) do { } while (0)
 #define SUBSTAMP_END(C, k) do { } while (0)
 #endif
+
+// Banded triangular sweeps with one lane per right-hand side (banded_system.hpp:96-118 and 123-145).
+// The reference's substitutions are column sweeps: step j finalises x(j) and updates the six following (or
+// preceding) entries of the same right-hand side.  The nine right-hand sides are independent, so lane d < 9 owns
+// column d of the 6N x 9 block and carries the six pending entries in registers: a step is six independent
+// multiply-subtracts with no LDS round trip and no barrier (the cross-lane version needed both, ~300 cycles per
+// step).  Arithmetic and its order per entry are unchanged (mul, then sub, j ascending / descending).
+//   MODE 0  L   x = b   (generate, forward):  b(i) -= A(i,j) b(j),            i = j+1..j+6
+//   MODE 1  U   x = b   (generate, backward): b(i) -= A(i,j) (b(j)/A(j,j)),   i = j-1..j-6 ; stores b(j)/A(j,j)
+//   MODE 2  U^T x = b   (adjoint, forward):   b(i) -= A(j,i) (b(j)/A(j,j)),   i = j+1..j+6 ; stores b(j)/A(j,j)
+//   MODE 3  L^T x = b   (adjoint, backward):  b(i) -= A(j,i) b(j),            i = j-1..j-6
+// rows = 6N is a multiple of 6: blocks of six steps with compile-time register indices.
+template <int MODE>
+__device__ __forceinline__ void band_sweep(lds_dp v, lds_cdp band, lds_cdp rdiag, int rows) {
+  constexpr bool FWD = (MODE == 0 || MODE == 2);
+  constexpr bool SCALE = (MODE == 1 || MODE == 2);
+  double w[6];
+  double x;
+  if (FWD) {
+    x = v[0];
+#pragma unroll
+    for (int t = 0; t < 6; t++) w[t] = v[1 + t];
+  } else {
+    x = v[rows - 1];
+#pragma unroll
+    for (int t = 0; t < 6; t++) w[t] = v[rows - 2 - t];
+  }
+  for (int b0 = 0; b0 < rows; b0 += 6) {
+    // everything the block reads from LDS, issued up front: 36 coefficients, 6 scales, 6 incoming entries
+    double cf[6][6], sc[6], nw[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
+#pragma unroll
+      for (int t = 1; t <= 6; t++) {
+        int idx;
+        if (MODE == 0) idx = (6 + t) * rows + j;            // A(j+t, j)
+        else if (MODE == 1) idx = (6 - t) * rows + j;       // A(j-t, j)
+        else if (MODE == 2) idx = (6 - t) * rows + j + t;   // A(j, j+t)
+        else idx = (6 + t) * rows + j - t;                  // A(j, j-t)
+        // Unconditional loads (a predicated load costs more than the arithmetic here).  The index stays inside the
+        // 13 x rows band array for every (j, t); where row i = j +- t falls outside the matrix the value read is a
+        // never-written zero (modes 0, 1) or an unrelated entry (modes 2, 3) and only ever feeds window slots of
+        // rows that do not exist and are never stored.
+        cf[u][t - 1] = band[idx];
+      }
+      if (SCALE) sc[u] = rdiag[j];
+      int in = FWD ? j + 7 : j - 7;
+      in = in < 0 ? 0 : (in > rows - 1 ? rows - 1 : in);
+      nw[u] = v[in];
+    }
+    double xo[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const double xs = SCALE ? x * sc[u] : x;
+      xo[u] = xs;
+#pragma unroll
+      for (int t = 0; t < 6; t++) w[(u + t) % 6] -= cf[u][t] * xs;
+      x = w[u % 6];
+      w[u % 6] = nw[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
+      v[j] = xo[u];
+    }
+  }
+}
 
 // MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
 // factors (+ reciprocal diagonal) stashed in C.lu.
@@ -398,24 +487,14 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   for (int t = lane; t < rows; t += 64) rdiag[t] = 1.0 / BAND(t, t);
   lds_sync();
   STAMP(C, 1);  // LU
-  // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118
+  // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118 (one lane per column)
   {
-    const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
-    for (int j = 0; j < rows; j++) {
-      const int i = j + t;
-      if (lane < 54 && i < rows) cL[d * rows + i] -= BAND(i, j) * cL[d * rows + j];
-      lds_sync();
+    SUBSTAMP_BEGIN(C);
+    if (lane < 9) {
+      band_sweep<0>(cL + lane * rows, band, rdiag, rows);
+      band_sweep<1>(cL + lane * rows, band, rdiag, rows);
     }
-    // rows stay unscaled during the sweep; b(j)/A(j,j) is formed on the fly and applied at the end
-    for (int j = rows - 1; j >= 0; j--) {
-      const int i = j - t;
-      if (lane < 54 && i >= 0) cL[d * rows + i] -= BAND(i, j) * (cL[d * rows + j] * rdiag[j]);
-      lds_sync();
-    }
-  }
-  for (int t = lane; t < 9 * rows; t += 64) {
-    const int row = t % rows;
-    cL[t] *= rdiag[row];
+    SUBSTAMP_END(C, 11);  // the two sweeps alone
   }
   // stash LU + reciprocal diagonal for the adjoint solve
   for (int t = lane; t < 14 * rows; t += 64) C.lu[t] = C.X[t];
@@ -504,6 +583,17 @@ struct ManiOut {
   double g[10];
   double cost, gdT;
 };
+#ifdef TOPAY_STAMPS
+__device__ long long g_mani_stamps[8];
+#define MSTAMP(k)                                                                                   \
+  do {                                                                                              \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();                                 \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_mani_stamps[k] += now_ - mt_;                        \
+    mt_ = now_;                                                                                     \
+  } while (0)
+#else
+#define MSTAMP(k) do { } while (0)
+#endif
 __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, const ManiIn in) {
   const DevParams& P = g_P;
   const DevMap M = load_map(mp);
@@ -514,12 +604,16 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
   double cost, gdTk;
   const double mu = P.relu_mu;
   const double w = omg * step;
+#ifdef TOPAY_STAMPS
+  long long mt_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
   double sq[7], cq[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) {
     det_sincos(pos[3 + i], &sq[i], &cq[i]);
-    __builtin_amdgcn_sched_barrier(0);
+    TOPAY_SCHED_FENCE();
   }
+  MSTAMP(0);  // 7 sincos
   double A[9];
   {
     const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
@@ -555,9 +649,10 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       q2 = fma(R[8], P.colli_length[i], q2);
       if (i == 7) break;
       joint_rotate(R, i, cq[i], sq[i]);
-      __builtin_amdgcn_sched_barrier(0);
+      TOPAY_SCHED_FENCE();
     }
   }
+  MSTAMP(1);  // walk 1
   double Gx[TOPAY_NSPH], Gy[TOPAY_NSPH], Gz[TOPAY_NSPH];
 #pragma unroll
   for (int k = 0; k < TOPAY_NSPH; k++) { Gx[k] = 0.0; Gy[k] = 0.0; Gz[k] = 0.0; }
@@ -582,10 +677,9 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
         gdTk += omg * wSC * (pe * TOPAY_INV_K);
         cost += w * wSC * pe;
       }
-      if (b == TOPAY_NSPH - 1) __builtin_amdgcn_sched_barrier(0);
     }
-  // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520), one sphere at a
-  // time: the scheduling barrier keeps at most one sphere's eight gathers in flight (register budget)
+  MSTAMP(2);  // sphere pairs
+  // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520)
   double bFx = 0.0, bFy = 0.0, bMz = 0.0;  // base: x, y, yaw (everything rotates about the vertical axis through (x, y))
 #pragma unroll
   for (int k = 0; k < TOPAY_NSPH; k++) {
@@ -618,8 +712,9 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     const double ty = fma(A[7], Gz[k], fma(A[4], Gy[k], A[1] * Gx[k]));
     const double tz = fma(A[8], Gz[k], fma(A[5], Gy[k], A[2] * Gx[k]));
     Gx[k] = tx; Gy[k] = ty; Gz[k] = tz;
-    __builtin_amdgcn_sched_barrier(0);
+    TOPAY_SCHED_FENCE();
   }
+  MSTAMP(3);  // ESDF loop
   moma_grad[0] = bFx;
   moma_grad[1] = bFy;
   moma_grad[2] = bMz;
@@ -647,7 +742,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       q2 = fma(R[8], P.colli_length[i], q2);
       if (i == 7) break;
       joint_rotate(R, i, cq[i], sq[i]);
-      __builtin_amdgcn_sched_barrier(0);
+      TOPAY_SCHED_FENCE();
     }
   }
   {
@@ -677,9 +772,10 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       const double tz = Mz - fma(o0, Fy, -(o1 * Fx));
       moma_grad[3 + i] = fma(az, tz, fma(ay, ty, ax * tx));
       joint_rotate(R, i, cq[i], sq[i]);
-      __builtin_amdgcn_sched_barrier(0);
+      TOPAY_SCHED_FENCE();
     }
   }
+  MSTAMP(4);  // walks 2a/2b
   // joint position limits — moma_traj_opt.cpp:1616-1666 (symmetric joint_pos_limit_max, reference quirk)
   const double wJP = P.s2_mani_pos_weight;
 #pragma unroll
@@ -701,6 +797,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       cost += w * wJP * pe;
     }
   }
+  MSTAMP(5);  // joint limits
   out.cost = cost;
   out.gdT = gdTk;
   return out;
@@ -924,7 +1021,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
             cst += omg * step * P.s2_mani_acc_weight * pe;
             jva = true;
           }
-          __builtin_amdgcn_sched_barrier(0);
+          TOPAY_SCHED_FENCE();
         }
         // park the per-sample context in this lane's LDS column while the manipulator block runs: it needs nearly
         // the whole register budget for the 12 sphere centres and their gradients
@@ -1244,20 +1341,14 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   }
   lds_sync();
   {
-    const int t = lane / 9 + 1, d = lane - (lane / 9) * 9;
-    for (int j = 0; j < rows; j++) {  // b(j) /= A(j,j); b(i) -= A(j,i) b(j), i = j+1..j+6
-      const int i = j + t;
-      if (lane < 54 && i < rows) adj[d * rows + i] -= BAND(j, i) * (adj[d * rows + j] * rdiag[j]);
-      lds_sync();
+    SUBSTAMP_BEGIN(C);
+    if (lane < 9) {  // one lane per column of the 6N x 9 block
+      band_sweep<2>(adj + lane * rows, band, rdiag, rows);  // b(j) /= A(j,j); b(i) -= A(j,i) b(j), i = j+1..j+6
+      band_sweep<3>(adj + lane * rows, band, rdiag, rows);  // b(i) -= A(j,i) b(j), i = j-6..j-1
     }
-    for (int tt = lane; tt < 9 * rows; tt += 64) adj[tt] *= rdiag[tt % rows];
-    lds_sync();
-    for (int j = rows - 1; j >= 0; j--) {  // b(i) -= A(j,i) b(j), i = j-6..j-1
-      const int i = j - t;
-      if (lane < 54 && i >= 0) adj[d * rows + i] -= BAND(j, i) * adj[d * rows + j];
-      lds_sync();
-    }
+    SUBSTAMP_END(C, 14);  // the two sweeps alone
   }
+  lds_sync();
   STAMP(C, 7);  // adjoint solve
   // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
   // each row lane forms its row's dot product, partial sums per piece go through rdiag[] (free now)

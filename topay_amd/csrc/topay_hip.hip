@@ -372,9 +372,10 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   if (!params || !out) return TOPAY_ERR_INVALID_ARG;
   if (params->int_K != TOPAY_K) { set_err("int_K must be 12 in this build"); return TOPAY_ERR_UNSUPPORTED; }
   if (!sphere_layout_ok(*params)) { set_err("unsupported collision sphere layout"); return TOPAY_ERR_UNSUPPORTED; }
-  if (params->s1_lbfgs.mem_size <= 0 || params->s2_lbfgs.mem_size <= 0 || params->s1_lbfgs.past > 8 ||
+  if (params->s1_lbfgs.mem_size <= 0 || params->s2_lbfgs.mem_size <= 0 || params->s1_lbfgs.mem_size > 256 ||
+      params->s2_lbfgs.mem_size > 256 || params->s1_lbfgs.past > 8 ||
       params->s2_lbfgs.past > 8 || params->s1_shot_path_past > 8 || params->s1_normal_past > 8) {
-    set_err("lbfgs mem_size must be > 0 and past <= 8");
+    set_err("lbfgs mem_size must be in 1..256 (the reference uses 256) and past <= 8");
     return TOPAY_ERR_INVALID_ARG;
   }
   int ndev = 0;
@@ -860,4 +861,12 @@ topay_status topay_last_kernel_ms(topay_ctx* c, double* ms, int* launches) {
   return TOPAY_OK;
 }
 
+
+#if defined(TOPAY_STAMPS) && !defined(TOPAY_CPU_EMU)
+// diagnostic build only: per-phase cycle counters of the manipulator block (lane 0 of block 0)
+topay_status topay_debug_mani_stamps(long long* out8) {
+  HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(topay::g_mani_stamps), 64));
+  return TOPAY_OK;
+}
+#endif
 }  // extern "C"

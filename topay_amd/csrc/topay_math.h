@@ -33,19 +33,16 @@ __device__ __forceinline__ double k_cos(double x, double y) {
   return w + (((1.0 - w) - hz) + (z * r - x * y));
 }
 
-// sin and cos of x
+// sin and cos of x.  Branch-free (so that independent calls can be interleaved by the scheduler: a single wave per
+// SIMD has nothing else to hide the ~15-deep dependent chain behind).
 __device__ __forceinline__ void det_sincos(double x, double* sn, double* cs) {
-  if (!(fabs(x) < 1.0e15)) {  // inf / nan / absurd: propagate a NaN deterministically
-    const double q = x - x;
-    *sn = q / q;
-    *cs = q / q;
-    return;
-  }
+  const bool bad = !(fabs(x) < 1.0e15);  // inf / nan / absurd: propagate a NaN deterministically
   const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
-  const double fn = rint(x * invpio2);
+  const double xs = bad ? 0.0 : x;
+  const double fn = rint(xs * invpio2);
   // two-step Cody-Waite reduction (e_rem_pio2.c, second iteration form)
-  const double t = x - fn * pio2_1;
+  const double t = xs - fn * pio2_1;
   double w = fn * pio2_2;
   const double r = t - w;
   w = fn * pio2_2t - ((t - r) - w);
@@ -53,8 +50,11 @@ __device__ __forceinline__ void det_sincos(double x, double* sn, double* cs) {
   const double y1 = (r - y0) - w;
   const double s = k_sin(y0, y1), c = k_cos(y0, y1);
   const int n = (int)((long long)fn & 3);
-  *sn = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
-  *cs = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const double so = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
+  const double co = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
+  *sn = bad ? nanv : so;
+  *cs = bad ? nanv : co;
 }
 
 __device__ __forceinline__ double det_atan(double xin) {

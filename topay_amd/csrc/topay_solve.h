@@ -11,6 +11,10 @@
 #pragma once
 #include "topay_eval.h"
 
+#ifndef TOPAY_PF_ELEMS
+#define TOPAY_PF_ELEMS 24
+#endif
+
 namespace topay {
 
 struct SolveIO {
@@ -195,7 +199,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             // two-loop recursion (lbfgs.hpp:691-710) with the direction held in registers (element e = lane + 64 t).
             // History pairs stream from HBM through a PF-deep register ring so that PF loads are always in flight
             // while the dependent dot-product / axpy chain runs.
-            constexpr int PF = 4;
+            // Only loads may be in flight inside the loops (one store would make the memory counter unordered and
+            // every wait a full drain), and every load is issued unconditionally so that the number outstanding is
+            // static: the alpha values live in a register ring (pair p -> lane p % 64, slot p / 64) and the prefetch
+            // keeps running past the end (it re-reads valid, unused rows).
+            constexpr int PF = TOPAY_PF_ELEMS / EPL;  // pairs in flight
             SUBSTAMP_BEGIN(C);
             double dr[EPL];
 #pragma unroll
@@ -203,24 +211,25 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
               const int e = lane + 64 * t;
               dr[t] = e < n ? -S.g[e] : 0.0;
             }
-            double sb[PF][EPL], yb[PF][EPL], rb[PF], ab[PF];
-            // ---- first loop: newest pair first.  Pair index of step i: (end - 1 - i) mod mem
-            auto load_pair = [&](int slot, int jj, bool with_alpha) {
+            double sb[PF][EPL], yb[PF][EPL], rb[PF];
+            double alr[4] = {0.0, 0.0, 0.0, 0.0};  // mem_size <= 256 (checked by topay_create)
+            auto load_pair = [&](int slot, int jj) {
               glb_cdp sj = S.hist_s + (size_t)jj * S.nstride;
               glb_cdp yj = S.hist_y + (size_t)jj * S.nstride;
 #pragma unroll
               for (int t = 0; t < EPL; t++) {
                 const int e = lane + 64 * t;
-                sb[slot][t] = e < n ? sj[e] : 0.0;
-                yb[slot][t] = e < n ? yj[e] : 0.0;
+                const int ec = e < n ? e : n - 1;
+                const double sv = sj[ec], yv = yj[ec];
+                sb[slot][t] = e < n ? sv : 0.0;
+                yb[slot][t] = e < n ? yv : 0.0;
               }
               rb[slot] = S.hist_ys[jj];
-              if (with_alpha) ab[slot] = S.hist_al[jj];
             };
+            // ---- first loop: newest pair first.  Pair index of step i: (end - 1 - i) mod mem
             int jl = end;  // next pair to load (walks down, wrapping)
 #pragma unroll
-            for (int u = 0; u < PF; u++)
-              if (u < bound) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl, false); }
+            for (int u = 0; u < PF; u++) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl); }
             int jlast = end, jc = end;  // jc: pair being processed
             for (int i0 = 0; i0 < bound; i0 += PF) {
 #pragma unroll
@@ -233,37 +242,46 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
                   const double al = wave_sum(part) * rb[u];
-                  S.hist_al[j] = al;
+                  {
+                    const int sl = j >> 6, ln = j & 63;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) alr[k] = (sl == k && lane == ln) ? al : alr[k];
+                  }
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
                   jlast = j;
-                  if (i + PF < bound) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl, false); }
                 }
+                jl = jl == 0 ? mem - 1 : jl - 1;
+                load_pair(u, jl);
               }
             }
             const double scl = ys / yy;
 #pragma unroll
             for (int t = 0; t < EPL; t++) dr[t] *= scl;
             // ---- second loop: oldest pair first.  Pair index of step i: (jlast + i) mod mem
-            __syncthreads();  // alpha values were stored by every lane; make sure they are back before re-reading
             jl = jlast;  // next pair to load (walks up, wrapping)
 #pragma unroll
-            for (int u = 0; u < PF; u++)
-              if (u < bound) { load_pair(u, jl, true); jl = jl + 1 == mem ? 0 : jl + 1; }
+            for (int u = 0; u < PF; u++) { load_pair(u, jl); jl = jl + 1 == mem ? 0 : jl + 1; }
+            jc = jlast;
             for (int i0 = 0; i0 < bound; i0 += PF) {
 #pragma unroll
               for (int u = 0; u < PF; u++) {
                 const int i = i0 + u;
                 if (i < bound) {
+                  const int j = jc;
+                  jc = jc + 1 == mem ? 0 : jc + 1;
                   double part = 0.0;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
                   const double beta = wave_sum(part) * rb[u];
-                  const double co = ab[u] - beta;
+                  const int sl = j >> 6, ln = j & 63;
+                  const double av = sl == 0 ? alr[0] : (sl == 1 ? alr[1] : (sl == 2 ? alr[2] : alr[3]));
+                  const double co = readlane_f64(av, ln) - beta;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
-                  if (i + PF < bound) { load_pair(u, jl, true); jl = jl + 1 == mem ? 0 : jl + 1; }
                 }
+                load_pair(u, jl);
+                jl = jl + 1 == mem ? 0 : jl + 1;
               }
             }
 #pragma unroll
