@@ -269,6 +269,7 @@ struct EvalCtx {
   lds_dp gdT;    // [N]        penalty dJ/dT accumulator
   lds_dp pcs;    // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
   lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
+  lds_dp pw;     // [26][6]    integer powers jj^k of the Simpson sample index (constant for the whole solve)
   lds_dp X;      // union region: band + reciprocal diagonal (14*rows) | sample buffers (26N + 960)
   // global
   glb_cdp x;
@@ -287,7 +288,7 @@ __host__ __device__ __forceinline__ int lds_doubles(int Nmax) {
   const int rows = 6 * Nmax;
   int xr = 14 * rows;
   int sr = 26 * Nmax + 960;
-  return 18 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + (xr > sr ? xr : sr);
+  return 18 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + 156 + (xr > sr ? xr : sr);
 }
 __device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
   const int rows = 6 * Nmax;
@@ -297,7 +298,19 @@ __device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
   C.gdT = C.hp + 54;
   C.pcs = C.gdT + Nmax;
   C.gC = C.pcs + 4 * (Nmax + 1);
-  C.X = C.gC + 9 * rows;
+  C.pw = C.gC + 9 * rows;
+  C.X = C.pw + 156;
+}
+// jj^k for jj = 0..25 (sample index within a piece; 25 is read but always multiplied by zero), k = 0..5: the local time of sample jj is jj * hs, so the
+// monomial basis of coefficient row k factors as (jj^k) * hs^k and the row lanes only need the three hs-powers
+// of their row (basis_k(k, hs)) once per pass instead of a power chain per sample.
+__device__ __forceinline__ void fill_power_table(lds_dp pw, int lane) {
+  for (int t = lane; t < 156; t += 64) {
+    const int jj = t / 6, k = t - 6 * jj;
+    double v = 1.0;
+    for (int u = 0; u < k; u++) v *= (double)jj;
+    pw[t] = v;
+  }
 }
 
 #define BAND(i, j) band[((i) - (j) + 6) * rows + (j)]
@@ -396,24 +409,36 @@ __device__ __forceinline__ void band_sweep(lds_dp v, lds_cdp band, lds_cdp rdiag
 // MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
 // factors (+ reciprocal diagonal) stashed in C.lu.
 __device__ __noinline__ void minco_generate(EvalCtx& C) {
+  // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
+  // is a flat (generic address space) load that the compiler must repeat after every LDS store.
+  const lds_dp c_Tp = C.Tp;
+  const lds_dp c_X = C.X;
+  const lds_dp c_gdT = C.gdT;
+  const lds_dp c_hp = C.hp;
+  const glb_dp c_lu = C.lu;
+  const glb_cdp c_x = C.x;
+
   const DevParams& P = g_P;
   const int lane = C.lane, N = C.N, rows = C.rows;
-  lds_dp band = C.X;
-  lds_dp rdiag = C.X + 13 * rows;
+  lds_dp band = c_X;
+  lds_dp rdiag = c_X + 13 * rows;
   lds_dp cL = C.cL;
-  glb_cdp Tau = C.x;
-  glb_cdp Theta = C.x + N;
-  glb_cdp Arc = C.x + 2 * N - 1;
-  glb_cdp Vq = C.x + 3 * N - 1;
+  glb_cdp Tau = c_x;
+  glb_cdp Theta = c_x + N;
+  glb_cdp Arc = c_x + 2 * N - 1;
+  glb_cdp Vq = c_x + 3 * N - 1;
 
   for (int t = lane; t < 13 * rows; t += 64) band[t] = 0.0;
-  for (int t = lane; t < 9 * rows; t += 64) { cL[t] = 0.0; C.gC[t] = 0.0; }
+  {
+    lds_dp gC0 = C.gC;
+    for (int t = lane; t < 9 * rows; t += 64) { cL[t] = 0.0; gC0[t] = 0.0; }
+  }
   if (lane < N) {
     double T1 = expC2(Tau[lane]);  // calTfromTau, moma_traj_opt.h:778-786
     double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
-    C.Tp[0 * N + lane] = T1; C.Tp[1 * N + lane] = T2; C.Tp[2 * N + lane] = T3;
-    C.Tp[3 * N + lane] = T4; C.Tp[4 * N + lane] = T5;
-    C.gdT[lane] = 0.0;
+    c_Tp[0 * N + lane] = T1; c_Tp[1 * N + lane] = T2; c_Tp[2 * N + lane] = T3;
+    c_Tp[3 * N + lane] = T4; c_Tp[4 * N + lane] = T5;
+    c_gdT[lane] = 0.0;
   }
   lds_sync();
   // band fill — minco.hpp:838-896
@@ -422,7 +447,7 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   }
   if (lane < N - 1) {
     const int i = lane;
-    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
     const int r = 6 * i;
     BAND(r + 3, r + 3) = 6.0;  BAND(r + 3, r + 4) = 24.0 * T1; BAND(r + 3, r + 5) = 60.0 * T2; BAND(r + 3, r + 9) = -6.0;
     BAND(r + 4, r + 4) = 24.0; BAND(r + 4, r + 5) = 120.0 * T1; BAND(r + 4, r + 10) = -24.0;
@@ -437,7 +462,7 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   }
   if (lane == 63) {
     const int i = N - 1, R0 = 6 * N;
-    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
     BAND(R0 - 3, R0 - 6) = 1.0; BAND(R0 - 3, R0 - 5) = T1; BAND(R0 - 3, R0 - 4) = T2; BAND(R0 - 3, R0 - 3) = T3;
     BAND(R0 - 3, R0 - 2) = T4; BAND(R0 - 3, R0 - 1) = T5;
     BAND(R0 - 2, R0 - 5) = 1.0; BAND(R0 - 2, R0 - 4) = 2 * T1; BAND(R0 - 2, R0 - 3) = 3 * T2; BAND(R0 - 2, R0 - 2) = 4 * T3;
@@ -447,12 +472,12 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   // right-hand side — minco.hpp:841-843, 879, 898-900; inner points from x (moma_traj_opt.cpp:904-913)
   if (lane < 9) {
     const int d = lane;
-    cL[d * rows + 0] = C.hp[0 * 9 + d];
-    cL[d * rows + 1] = C.hp[1 * 9 + d];
-    cL[d * rows + 2] = C.hp[2 * 9 + d];
-    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : C.hp[27 + 0 * 9 + d];  // minco_end_state(1,0) = Arc[N-1]
-    cL[d * rows + rows - 2] = C.hp[27 + 1 * 9 + d];
-    cL[d * rows + rows - 1] = C.hp[27 + 2 * 9 + d];
+    cL[d * rows + 0] = c_hp[0 * 9 + d];
+    cL[d * rows + 1] = c_hp[1 * 9 + d];
+    cL[d * rows + 2] = c_hp[2 * 9 + d];
+    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : c_hp[27 + 0 * 9 + d];  // minco_end_state(1,0) = Arc[N-1]
+    cL[d * rows + rows - 2] = c_hp[27 + 1 * 9 + d];
+    cL[d * rows + rows - 1] = c_hp[27 + 2 * 9 + d];
   }
   for (int t = lane; t < 9 * (N - 1); t += 64) {
     const int i = t / 9, d = t - 9 * i;
@@ -494,10 +519,10 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
       band_sweep<0>(cL + lane * rows, band, rdiag, rows);
       band_sweep<1>(cL + lane * rows, band, rdiag, rows);
     }
-    SUBSTAMP_END(C, 11);  // the two sweeps alone
+    SUBSTAMP_END(C, 9);  // (diagnostic experiment: folded into slot 9)
   }
   // stash LU + reciprocal diagonal for the adjoint solve
-  for (int t = lane; t < 14 * rows; t += 64) C.lu[t] = C.X[t];
+  for (int t = lane; t < 14 * rows; t += 64) c_lu[t] = c_X[t];
   lds_sync();
   STAMP(C, 2);  // substitutions + stash
 }
@@ -880,6 +905,26 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 // ---------------------------------------------------------------------------------------------
 template <int STAGE, int RMAX>
 __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp) {
+  // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
+  // is a flat (generic address space) load that the compiler must repeat after every LDS store.
+  const lds_dp c_Tp = C.Tp;
+  const lds_dp c_X = C.X;
+  const double c_ex = C.ex;
+  const double c_ey = C.ey;
+  const glb_dp c_g = C.g;
+  const lds_dp c_gdT = C.gdT;
+  const glb_cdp c_init_xy = C.init_xy;
+  const double c_lam0 = C.lam0;
+  const double c_lam1 = C.lam1;
+  const glb_dp c_lu = C.lu;
+  const lds_dp c_pcs = C.pcs;
+  const lds_dp c_pw = C.pw;
+  const double c_rho0 = C.rho0;
+  const double c_rho1 = C.rho1;
+  const double c_sx = C.sx;
+  const double c_sy = C.sy;
+  const glb_cdp c_x = C.x;
+
   const DevParams& P = g_P;
   const int lane = C.lane, N = C.N, rows = C.rows;
   lds_cdp cL = C.cL;
@@ -897,7 +942,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       w33 += (c3 * e) * c3; w43 += (c4 * e) * c3; w44 += (c4 * e) * c4;
       w53 += (c5 * e) * c3; w54 += (c5 * e) * c4; w55 += (c5 * e) * c5;
     }
-    const double T1 = C.Tp[i], T2 = C.Tp[N + i], T3 = C.Tp[2 * N + i], T4 = C.Tp[3 * N + i], T5 = C.Tp[4 * N + i];
+    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
     jerk_e = 36.0 * w33 * T1 + 144.0 * w43 * T2 + 192.0 * w44 * T3 + 240.0 * w53 * T3 + 720.0 * w54 * T4 + 720.0 * w55 * T5;
     jerk_gdT = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
   }
@@ -916,8 +961,8 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   }
   lds_dp gC = C.gC;
 
-  lds_dp gxy = C.X;                  // [13N][2] positional gradient of each even sample
-  lds_dp pbuf = C.X + 26 * N;        // [15][64] pass buffer (also the per-lane stash around the manipulator block)
+  lds_dp gxy = c_X;                  // [13N][2] positional gradient of each even sample
+  lds_dp pbuf = c_X + 26 * N;        // [15][64] pass buffer (also the per-lane stash around the manipulator block)
   const int NE = TOPAY_EP * N;       // even samples
   const int npass = (NE + 63) / 64;
   double cost_pen = 0.0;             // per-lane partial penalty cost
@@ -929,12 +974,15 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 
   // =========================== sweep 1: forward over even samples ===========================
   for (int pass = 0; pass < npass; pass++) {
+#ifdef TOPAY_STAMPS
+    const long long pro_t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int e = pass * 64 + lane;
     const bool act = e < NE;
     const int i = act ? e / TOPAY_EP : N - 1;
     const int m = act ? e - TOPAY_EP * i : 0;
     const int j = 2 * m;
-    const double T1 = C.Tp[i];
+    const double T1 = c_Tp[i];
     const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
     // Simpson panel m of piece i: samples j, j+1, j+2 — moma_traj_opt.cpp:1282-1291, 1731-1732
     double f0x, f0y, Ix = 0.0, Iy = 0.0;
@@ -947,14 +995,14 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       Iy = coeff * f0y + 4 * coeff * f1y + coeff * f2y;
     }
     const double incx = wave_incl_scan(Ix, lane), incy = wave_incl_scan(Iy, lane);
-    const double posx = C.sx + (carryx + (incx - Ix));  // CurrentXY at this even sample
-    const double posy = C.sy + (carryy + (incy - Iy));
+    const double posx = c_sx + (carryx + (incx - Ix));  // CurrentXY at this even sample
+    const double posy = c_sy + (carryy + (incy - Iy));
     const double totx = __shfl(incx, 63), toty = __shfl(incy, 63);
     carryx += totx;
     carryy += toty;
     if (act && m == TOPAY_K) {  // piece end: VecTrajFinalXY[i+1] — moma_traj_opt.cpp:1750
-      C.pcs[2 * N + 2 * (i + 1)] = posx;
-      C.pcs[2 * N + 2 * (i + 1) + 1] = posy;
+      c_pcs[2 * N + 2 * (i + 1)] = posx;
+      c_pcs[2 * N + 2 * (i + 1) + 1] = posy;
     }
 
     double gB[12];
@@ -962,6 +1010,9 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     for (int v = 0; v < 12; v++) gB[v] = 0.0;
     double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
     bool jva = false;
+#ifdef TOPAY_STAMPS
+    (void)pro_t0_;
+#endif
     SUBSTAMP_BEGIN(C);
     if (act) {
       Basis B;
@@ -1062,62 +1113,88 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       cost_pen += cst;
     }
     SUBSTAMP_END(C, 12);  // sample body of lane 0
+#ifdef TOPAY_STAMPS
+    const long long rnd_t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (act) {
       gxy[2 * e] = gpx;
       gxy[2 * e + 1] = gpy;
     }
-    // ---- hand the per-sample gradient rows to the row lanes.  Round A: theta/s rows + gdT
+    // ---- hand the per-sample gradient rows to the row lanes: theta/s rows (orders 0-2), gdT and, in stage 2, the
+    // order-0 joint rows, in ONE round.  Row lane (piece pi, power k) accumulates over the samples of its piece that
+    // belong to this pass, three at a time with every LDS operand fetched before the arithmetic starts (a single
+    // wave per SIMD has no other way to overlap the LDS latency); sample order and the arithmetic per sample are
+    // unchanged, padding samples of the last chunk are masked.
+    double rbh[RMAX][3];  // hs-powers of each row of this lane (basis_k(k, hs)), also used by the rare round below
+    constexpr int NV = (STAGE == 2) ? 13 : 6;
 #pragma unroll
     for (int v = 0; v < 5; v++) pbuf[v * 64 + lane] = gB[v];
     pbuf[5 * 64 + lane] = gdTs;
+    if (STAGE == 2) {
+#pragma unroll
+      for (int v = 0; v < 7; v++) pbuf[(6 + v) * 64 + lane] = gB[5 + v];
+    }
     lds_sync();
 #pragma unroll
     for (int r = 0; r < RMAX; r++) {
       if (ract[r]) {
         const int pi = rpiece[r];
         const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-        const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+        const double hs = c_Tp[pi] / TOPAY_K / 2.0;
+        double h0, h1, h2;
+        basis_k(rk[r], hs, h0, h1, h2);
+        rbh[r][0] = h0; rbh[r][1] = h1; rbh[r][2] = h2;
+        const int k0 = rk[r], k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
         double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
-        for (int ee = e_lo; ee < e_hi; ee++) {
-          const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-          double b0, b1, b2;
-          basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
-          a0 += fma(b2, pbuf[2 * 64 + l], fma(b1, pbuf[1 * 64 + l], b0 * pbuf[0 * 64 + l]));
-          a1 += fma(b2, pbuf[4 * 64 + l], b1 * pbuf[3 * 64 + l]);
-          gt += pbuf[5 * 64 + l];
+        double aq[7];
+        if (STAGE == 2) {
+#pragma unroll
+          for (int q = 0; q < 7; q++) aq[q] = gC[(2 + q) * rows + rrow[r]];
+        }
+        constexpr int CH = 3;
+        for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
+          double pb[CH][NV], t0[CH], t1[CH], t2[CH];
+#pragma unroll
+          for (int u = 0; u < CH; u++) {
+            const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
+            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+            lds_cdp pj = c_pw + 12 * mm;  // row of jj = 2 mm
+            t0[u] = pj[k0]; t1[u] = pj[k1]; t2[u] = pj[k2];
+#pragma unroll
+            for (int v = 0; v < NV; v++) pb[u][v] = pbuf[v * 64 + l];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; u++) {
+            const bool ok = c0 + u < e_hi;
+            const double b0 = h0 * t0[u], b1 = h1 * t1[u], b2 = h2 * t2[u];
+            const double i0 = fma(b2, pb[u][2], fma(b1, pb[u][1], b0 * pb[u][0]));
+            const double i1 = fma(b2, pb[u][4], b1 * pb[u][3]);
+            a0 += ok ? i0 : 0.0;
+            a1 += ok ? i1 : 0.0;
+            gt += ok ? pb[u][5] : 0.0;
+            if (STAGE == 2) {
+#pragma unroll
+              for (int q = 0; q < 7; q++) {
+                const double nq = fma(b0, pb[u][6 + q], aq[q]);
+                aq[q] = ok ? nq : aq[q];
+              }
+            }
+          }
         }
         gC[0 * rows + rrow[r]] = a0;
         gC[1 * rows + rrow[r]] = a1;
-        if (rk[r] == 0) C.gdT[pi] += gt;
-      }
-    }
-    lds_sync();
-    if (STAGE == 2) {
-      // Round B: joint rows of order 0
-#pragma unroll
-      for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = gB[5 + v];
-      lds_sync();
-#pragma unroll
-      for (int r = 0; r < RMAX; r++) {
-        if (ract[r]) {
-          const int pi = rpiece[r];
-          const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-          const double hs = C.Tp[pi] / TOPAY_K / 2.0;
-          double aq[7];
-#pragma unroll
-          for (int q = 0; q < 7; q++) aq[q] = gC[(2 + q) * rows + rrow[r]];
-          for (int ee = e_lo; ee < e_hi; ee++) {
-            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-            double b0, b1, b2;
-            basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
-#pragma unroll
-            for (int q = 0; q < 7; q++) aq[q] = fma(b0, pbuf[q * 64 + l], aq[q]);
-          }
+        if (STAGE == 2) {
 #pragma unroll
           for (int q = 0; q < 7; q++) gC[(2 + q) * rows + rrow[r]] = aq[q];
         }
+        if (rk[r] == 0) c_gdT[pi] += gt;
       }
-      lds_sync();
+    }
+    lds_sync();
+#ifdef TOPAY_STAMPS
+    if (C.stamps && lane == 0) C.stamps[15] += (long long)__builtin_amdgcn_s_memtime() - rnd_t0_;
+#endif
+    if (STAGE == 2) {
       // Round C (rare): joint velocity / acceleration gradBeta rows 1 and 2 — moma_traj_opt.cpp:1689, 1703.
       // Few samples ever trigger these limits, so the flagged lanes are visited one at a time (wave-uniform loop
       // over the ballot): the lane's 14 values are broadcast and every row lane of its piece adds its own entry.
@@ -1160,9 +1237,8 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #pragma unroll
           for (int r = 0; r < RMAX; r++) {
             if (ract[r] && rpiece[r] == spi) {
-              const double hs = C.Tp[spi] / TOPAY_K / 2.0;
-              double b0, b1, b2;
-              basis_k(rk[r], (2 * smm) * hs, b0, b1, b2);
+              const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
+              const double b1 = rbh[r][1] * c_pw[12 * smm + k1], b2 = rbh[r][2] * c_pw[12 * smm + k2];
 #pragma unroll
               for (int q = 0; q < 7; q++) {
                 double a = gC[(2 + q) * rows + rrow[r]];
@@ -1176,6 +1252,9 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
         lds_sync();
       }
     }
+#ifdef TOPAY_STAMPS
+    if (C.stamps && lane == 0) C.stamps[11] += (long long)__builtin_amdgcn_s_memtime() - rnd_t0_;
+#endif
   }
 
   STAMP(C, 4);  // sweep 1
@@ -1186,16 +1265,16 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
     lds_sync();
     if (lane < N) {
-      const double ex = C.pcs[2 * N + 2 * (lane + 1)] - C.init_xy[2 * lane];
-      const double ey = C.pcs[2 * N + 2 * (lane + 1) + 1] - C.init_xy[2 * lane + 1];
+      const double ex = c_pcs[2 * N + 2 * (lane + 1)] - c_init_xy[2 * lane];
+      const double ey = c_pcs[2 * N + 2 * (lane + 1) + 1] - c_init_xy[2 * lane + 1];
       cost_piece = P.s1_path_pos_weight * (ex * ex + ey * ey);
-      C.pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
-      C.pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
+      c_pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
+      c_pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
     }
     lds_sync();
   } else {
     // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
-    const double Tm = lane < N ? C.Tp[lane] : 0.0;
+    const double Tm = lane < N ? c_Tp[lane] : 0.0;
     const double avg = wave_sum(Tm) / N;
     double add_all = 0.0, add_own = 0.0;
     if (lane < N) {
@@ -1214,14 +1293,14 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       }
     }
     const double all = wave_sum(add_all);
-    if (lane < N) C.gdT[lane] += all + add_own;
+    if (lane < N) c_gdT[lane] += all + add_own;
     // ALM end-point term — moma_traj_opt.cpp:1785-1810
-    C.fxe0 = (C.sx + carryx) - C.ex;
-    C.fxe1 = (C.sy + carryy) - C.ey;
-    const double ea = C.fxe0 + C.lam0 / C.rho0, eb = C.fxe1 + C.lam1 / C.rho1;
-    if (lane == 0) cost_piece += 0.5 * (C.rho0 * (ea * ea) + C.rho1 * (eb * eb));
-    chain0x = C.rho0 * ea;
-    chain0y = C.rho1 * eb;
+    C.fxe0 = (c_sx + carryx) - c_ex;
+    C.fxe1 = (c_sy + carryy) - c_ey;
+    const double ea = C.fxe0 + c_lam0 / c_rho0, eb = C.fxe1 + c_lam1 / c_rho1;
+    if (lane == 0) cost_piece += 0.5 * (c_rho0 * (ea * ea) + c_rho1 * (eb * eb));
+    chain0x = c_rho0 * ea;
+    chain0y = c_rho1 * eb;
   }
   double penalty_cost = wave_sum(cost_pen + cost_piece);
   // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
@@ -1249,13 +1328,13 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       } else {
         // stage 1: chain of piece i = sum of tracking gradients of pieces > i (head(i*(2K+1)) quirk)
         double sx_ = 0.0, sy_ = 0.0;
-        for (int ii = i + 1; ii < N; ii++) { sx_ += C.pcs[2 * ii]; sy_ += C.pcs[2 * ii + 1]; }
+        for (int ii = i + 1; ii < N; ii++) { sx_ += c_pcs[2 * ii]; sy_ += c_pcs[2 * ii + 1]; }
         chx_in = chx_ex = sx_;
         chy_in = chy_ex = sy_;
       }
       double v0 = 0, v1 = 0, v2 = 0, v3 = 0, vT = 0;
       if (act) {
-        const double T1 = C.Tp[i];
+        const double T1 = c_Tp[i];
         const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
         const int int_6K = TOPAY_K * 6;
 #pragma unroll
@@ -1289,20 +1368,38 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
         if (ract[r]) {
           const int pi = rpiece[r];
           const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-          const double hs = C.Tp[pi] / TOPAY_K / 2.0;
+          const double hs = c_Tp[pi] / TOPAY_K / 2.0;
+          double h0, h1, h2;
+          basis_k(rk[r], hs, h0, h1, h2);
+          const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0;
           double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
-          for (int ee = e_lo; ee < e_hi; ee++) {
-            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-            double b0, b1, b2, o0, o1, o2;
-            basis_k(rk[r], (2 * mm) * hs, b0, b1, b2);
-            basis_k(rk[r], (2 * mm + 1) * hs, o0, o1, o2);
-            a0 += fma(o0, pbuf[2 * 64 + l], b0 * pbuf[0 * 64 + l]);
-            a1 += fma(o1, pbuf[3 * 64 + l], b1 * pbuf[1 * 64 + l]);
-            gt += pbuf[4 * 64 + l];
+          constexpr int CH = 3;  // samples per chunk, operands fetched up front (see sweep 1)
+          for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
+            double pb[CH][5], tb[CH][4];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+              const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
+              const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+              lds_cdp pj = c_pw + 12 * mm;  // rows jj = 2 mm (even sample) and 2 mm + 1 (the odd sample after it)
+              tb[u][0] = pj[rk[r]]; tb[u][1] = pj[k1]; tb[u][2] = pj[6 + rk[r]]; tb[u][3] = pj[6 + k1];
+#pragma unroll
+              for (int v = 0; v < 5; v++) pb[u][v] = pbuf[v * 64 + l];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+              const bool ok = c0 + u < e_hi;
+              const double b0 = h0 * tb[u][0], b1 = h1 * tb[u][1];
+              const double o0 = h0 * tb[u][2], o1 = h1 * tb[u][3];
+              const double i0 = fma(o0, pb[u][2], b0 * pb[u][0]);
+              const double i1 = fma(o1, pb[u][3], b1 * pb[u][1]);
+              a0 += ok ? i0 : 0.0;
+              a1 += ok ? i1 : 0.0;
+              gt += ok ? pb[u][4] : 0.0;
+            }
           }
           gC[0 * rows + rrow[r]] = a0;
           gC[1 * rows + rrow[r]] = a1;
-          if (rk[r] == 0) C.gdT[pi] += gt;
+          if (rk[r] == 0) c_gdT[pi] += gt;
         }
       }
       lds_sync();
@@ -1310,21 +1407,21 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   } else {
     penalty_cost = 1.0e+22;
     for (int t = lane; t < 9 * rows; t += 64) gC[t] = 0.0;
-    if (lane < N) C.gdT[lane] = 0.0;
+    if (lane < N) c_gdT[lane] = 0.0;
     lds_sync();
   }
 
   STAMP(C, 6);  // sweep 2
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
-  lds_dp band = C.X;
-  lds_dp rdiag = C.X + 13 * rows;
+  lds_dp band = c_X;
+  lds_dp rdiag = c_X + 13 * rows;
   lds_dp adj = C.gC;             // [9][rows]: the adjoint solve runs in place on the dJ/dC accumulator
-  for (int t = lane; t < 14 * rows; t += 64) C.X[t] = C.lu[t];
+  for (int t = lane; t < 14 * rows; t += 64) c_X[t] = c_lu[t];
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
     if (ract[r]) {
       const int pi = rpiece[r], k = rk[r];
-      const double T1 = C.Tp[pi], T2 = C.Tp[N + pi], T3 = C.Tp[2 * N + pi], T4 = C.Tp[3 * N + pi], T5 = C.Tp[4 * N + pi];
+      const double T1 = c_Tp[pi], T2 = c_Tp[N + pi], T3 = c_Tp[2 * N + pi], T4 = c_Tp[3 * N + pi], T5 = c_Tp[4 * N + pi];
 #pragma unroll
       for (int d = 0; d < 9; d++) {
         double jg = 0.0;
@@ -1364,7 +1461,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       else { pi = (row - 3) / 6; br = (row - 3) - 6 * pi; }
       double part = 0.0;
       if (use) {
-        const double T1 = C.Tp[pi], T2 = C.Tp[N + pi], T3 = C.Tp[2 * N + pi], T4 = C.Tp[3 * N + pi];
+        const double T1 = c_Tp[pi], T2 = c_Tp[N + pi], T3 = c_Tp[2 * N + pi], T4 = c_Tp[3 * N + pi];
 #pragma unroll
         for (int d = 0; d < 9; d++) {
           lds_cdp c = cL + d * rows + 6 * pi;
@@ -1388,25 +1485,25 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     double s = 0.0;
     if (i < N - 1) { for (int r = 0; r < 6; r++) s += rdiag[6 * i + 3 + r]; }
     else { for (int r = 0; r < 3; r++) s += rdiag[rows - 3 + r]; }
-    gdT_tot = jerk_gdT + C.gdT[i] + s;
+    gdT_tot = jerk_gdT + c_gdT[i] + s;
   }
   // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948
   const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
-  glb_cdp Tau = C.x;
-  glb_cdp Vq = C.x + 3 * N - 1;
+  glb_cdp Tau = c_x;
+  glb_cdp Vq = c_x + 3 * N - 1;
   double tsum = 0.0;
   if (lane < N) {
-    C.g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
-    tsum = C.Tp[lane];
+    c_g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
+    tsum = c_Tp[lane];
   }
   for (int t = lane; t < 9 * (N - 1); t += 64) {
     const int i = t / 9, d = t - 9 * i;
     const double gp = adj[d * rows + 6 * i + 5];  // gdP.col(i) = adjGrad.row(6i+5)
-    if (d == 0) C.g[N + i] = gp;
-    else if (d == 1) C.g[2 * N - 1 + i] = gp;
-    else C.g[3 * N - 1 + 7 * i + (d - 2)] = gp * dQdVq(Vq[7 * i + d - 2], P.joint_pos_limit_max[d - 2]);
+    if (d == 0) c_g[N + i] = gp;
+    else if (d == 1) c_g[2 * N - 1 + i] = gp;
+    else c_g[3 * N - 1 + 7 * i + (d - 2)] = gp * dQdVq(Vq[7 * i + d - 2], P.joint_pos_limit_max[d - 2]);
   }
-  if (lane == 0) C.g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
+  if (lane == 0) c_g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
   const double time_cost = wT * wave_sum(tsum);
   __syncthreads();  // g (global memory) becomes visible to the lanes that read it next
   STAMP(C, 8);  // gradient assembly

@@ -49,6 +49,7 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
   carve(C, TOPAY_LDS_PTR, Nmax_lds);
+  fill_power_table(C.pw, C.lane);
   for (int t = C.lane; t < 27; t += 64) {
     C.hp[t] = Bt.head[(size_t)b * 27 + t];
     C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
