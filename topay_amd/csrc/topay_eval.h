@@ -39,6 +39,10 @@ __constant__ DevParams g_P;
 #define TOPAY_SCHED_FENCE() do { } while (0)
 #endif
 
+#ifndef TOPAY_ESDF_LOOKAHEAD
+#define TOPAY_ESDF_LOOKAHEAD 2
+#endif
+
 namespace topay {
 
 // ---------------------------------------------------------------------------------------------
@@ -255,6 +259,56 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
     gx = g0 * ri;
   }
   dist = in ? dist : 0.0; gx = in ? gx : 0.0; gy = in ? gy : 0.0; gz = in ? gz : 0.0;
+}
+
+// The same lookup split in two so that the gathers of the next sphere can be in flight while the penalties of the
+// current one (divergent branches the scheduler will not move loads across) are evaluated.
+struct Esdf3dReq {
+  double v000, v001, v010, v011, v100, v101, v110, v111;
+  double dx, dy, dz;
+  bool in;
+};
+__device__ __forceinline__ void esdf3d_issue(const DevMap& M, double px, double py, double pz, Esdf3dReq& q) {
+  q.in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || pz < M.min_b[2] + 1e-4 ||
+           px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4 || pz > M.max_b[2] - 1e-4);
+  const double r = M.res, ri = M.res_inv;
+  int ix = (int)floor((px - 0.5 * r - M.origin[0]) * ri);
+  int iy = (int)floor((py - 0.5 * r - M.origin[1]) * ri);
+  int iz = (int)floor((pz - 0.5 * r - M.origin[2]) * ri);
+  q.dx = (px - ((ix + 0.5) * r + M.origin[0])) * ri;
+  q.dy = (py - ((iy + 0.5) * r + M.origin[1])) * ri;
+  q.dz = (pz - ((iz + 0.5) * r + M.origin[2])) * ri;
+  const int ny = M.dims[1], nz = M.dims[2];
+  int x0, x1, y0, y1, z0, z1;
+  clamp_pair(ix, M.dims[0] - 1, x0, x1);
+  clamp_pair(iy, ny - 1, y0, y1);
+  clamp_pair(iz, nz - 1, z0, z1);
+  glb_cdp e = M.esdf3d;
+  size_t b00 = ((size_t)x0 * ny + y0) * nz, b01 = ((size_t)x0 * ny + y1) * nz;
+  size_t b10 = ((size_t)x1 * ny + y0) * nz, b11 = ((size_t)x1 * ny + y1) * nz;
+  q.v000 = e[b00 + z0]; q.v001 = e[b00 + z1]; q.v010 = e[b01 + z0]; q.v011 = e[b01 + z1];
+  q.v100 = e[b10 + z0]; q.v101 = e[b10 + z1]; q.v110 = e[b11 + z0]; q.v111 = e[b11 + z1];
+}
+__device__ __forceinline__ void esdf3d_finish(const DevMap& M, const Esdf3dReq& q, double& dist, double& gx, double& gy,
+                                              double& gz) {
+  const double ri = M.res_inv;
+  const double dx = q.dx, dy = q.dy, dz = q.dz;
+  const double ex = 1 - dx, ey = 1 - dy, ez = 1.0 - dz;
+  double v00 = fma(q.v100, dx, q.v000 * ex);
+  double v01 = fma(q.v101, dx, q.v001 * ex);
+  double v10 = fma(q.v110, dx, q.v010 * ex);
+  double v11 = fma(q.v111, dx, q.v011 * ex);
+  double v0 = fma(v10, dy, v00 * ey);
+  double v1 = fma(v11, dy, v01 * ey);
+  dist = fma(v1, dz, v0 * ez);
+  gz = (v1 - v0) * ri;
+  gy = fma(v11 - v01, dz, (v10 - v00) * ez) * ri;
+  double g0 = ez * ey * (q.v100 - q.v000);
+  g0 = fma(ez * dy, q.v110 - q.v010, g0);
+  g0 = fma(dz * ey, q.v101 - q.v001, g0);
+  g0 = fma(dz * dy, q.v111 - q.v011, g0);
+  gx = g0 * ri;
+  dist = q.in ? dist : 0.0; gx = q.in ? gx : 0.0; gy = q.in ? gy : 0.0; gz = q.in ? gz : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,28 +740,47 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
   const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
   // sphere pairs: collision_matrix == -1 <=> non-adjacent spheres (moma_param.h:128-143: at the zero pose
   // only self and neighbouring spheres overlap) — moma_traj_opt.cpp:1566-1611
+  // One branch per sphere a instead of one per pair: the clearances of (a, b > a+1) are independent straight-line
+  // arithmetic (instruction-level parallelism is all a single wave per SIMD has), and only a lane that sees a
+  // positive one walks the penalty path, which recomputes the same expressions.
 #pragma unroll
-  for (int a = 0; a < TOPAY_NSPH; a++)
+  for (int a = 0; a < TOPAY_NSPH - 2; a++) {
+    double worst = -1.0;
 #pragma unroll
     for (int b = a + 2; b < TOPAY_NSPH; b++) {
       const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
       const double rr = P.sph_r[a] + P.sph_r[b];
       const double dist = rr * rr - fma(dz, dz, fma(dy, dy, dx * dx));
-      if (dist > 0) {
-        double pe, pd;
-        smoothL1(dist, mu, pe, pd);
-        const double sc = -w * wSC * pd * 2.0;
-        Gx[a] = fma(sc, dx, Gx[a]); Gy[a] = fma(sc, dy, Gy[a]); Gz[a] = fma(sc, dz, Gz[a]);
-        Gx[b] = fma(-sc, dx, Gx[b]); Gy[b] = fma(-sc, dy, Gy[b]); Gz[b] = fma(-sc, dz, Gz[b]);
-        gdTk += omg * wSC * (pe * TOPAY_INV_K);
-        cost += w * wSC * pe;
+      worst = fmax(worst, dist);
+    }
+    if (worst > 0) {
+#pragma unroll
+      for (int b = a + 2; b < TOPAY_NSPH; b++) {
+        const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
+        const double rr = P.sph_r[a] + P.sph_r[b];
+        const double dist = rr * rr - fma(dz, dz, fma(dy, dy, dx * dx));
+        if (dist > 0) {
+          double pe, pd;
+          smoothL1(dist, mu, pe, pd);
+          const double sc = -w * wSC * pd * 2.0;
+          Gx[a] = fma(sc, dx, Gx[a]); Gy[a] = fma(sc, dy, Gy[a]); Gz[a] = fma(sc, dz, Gz[a]);
+          Gx[b] = fma(-sc, dx, Gx[b]); Gy[b] = fma(-sc, dy, Gy[b]); Gz[b] = fma(-sc, dz, Gz[b]);
+          gdTk += omg * wSC * (pe * TOPAY_INV_K);
+          cost += w * wSC * pe;
+        }
       }
     }
+  }
   MSTAMP(2);  // sphere pairs
   // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520)
   double bFx = 0.0, bFy = 0.0, bMz = 0.0;  // base: x, y, yaw (everything rotates about the vertical axis through (x, y))
+  constexpr int LA = TOPAY_ESDF_LOOKAHEAD;  // spheres whose gathers are issued ahead
+  Esdf3dReq rq[LA + 1];
+#pragma unroll
+  for (int k = 0; k < LA; k++) esdf3d_issue(M, Px[k], Py[k], Pz[k], rq[k]);
 #pragma unroll
   for (int k = 0; k < TOPAY_NSPH; k++) {
+    if (k + LA < TOPAY_NSPH) esdf3d_issue(M, Px[k + LA], Py[k + LA], Pz[k + LA], rq[(k + LA) % (LA + 1)]);
     if (k >= 3) {
       const double height = P.chassis_height + P.relT[2] + P.sph_r[k] - Pz[k];
       if (height > 0) {
@@ -719,7 +792,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       }
     }
     double d, gx, gy, gz;
-    esdf3d_query(M, Px[k], Py[k], Pz[k], d, gx, gy, gz);
+    esdf3d_finish(M, rq[k % (LA + 1)], d, gx, gy, gz);
     const double viola = P.sph_r[k] * 10.0 * 1.1 - d * 10.0;
     if (viola > 0) {
       double pe, pd;
