@@ -184,6 +184,10 @@ topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
  * device clock (only differences are meaningful).  Either pointer may be NULL. */
 topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
 
+/* ALM state (alm_lambda[2], alm_rho[2]) every candidate finished with; traj_cost is the stage-2 cost at the returned x
+ * with this state (moma_traj_opt.cpp:398-401, 456-459). */
+topay_status topay_get_alm(topay_ctx* ctx, double* alm /* batch x 4: lambda0, lambda1, rho0, rho1 */);
+
 /* Number of decision variables of candidate i (n = 10N - 8) and the packed vector
  * x = [tau(N) | theta(N-1) | s(N) | Vq(7 x (N-1), column = knot)] (moma_traj_opt.cpp:324-344). */
 topay_status topay_get_x(topay_ctx* ctx, int i, int* n, double* x);

@@ -85,6 +85,7 @@ def load(path=None):
     L.topay_get_batch.argtypes = [C.c_void_p, c_ip, c_dp, c_ip]
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
+    L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
     L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp]
     L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -208,6 +209,12 @@ class MomaTrajOptBatch:
         s = np.zeros(self.batch * 8, dtype=np.int32)
         _chk(self.L, self.L.topay_get_stats(self.h, _ip(s)))
         return s.reshape(self.batch, 8)
+
+    def alm_state(self):
+        """(lambda0, lambda1, rho0, rho1) every candidate finished with."""
+        a = np.zeros(self.batch * 4)
+        _chk(self.L, self.L.topay_get_alm(self.h, _dp(a)))
+        return a.reshape(self.batch, 4)
 
     def elapsed_us(self):
         """Device-measured optimisation time of every candidate (microseconds)."""

@@ -688,6 +688,13 @@ topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us) {
   return TOPAY_OK;
 }
 
+topay_status topay_get_alm(topay_ctx* c, double* alm) {
+  if (!c || !c->have_traj || !alm) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(alm, c->alm.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
 topay_status topay_get_stats(topay_ctx* c, int* stats) {
   if (!c || !c->have_traj || !stats) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
