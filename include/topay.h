@@ -165,6 +165,13 @@ topay_status topay_reset(topay_ctx* ctx);
 /* == optimizeTraj lines 359-497 for every batch member (stage-1 L-BFGS, stage-2 ALM loop). */
 topay_status topay_optimize(topay_ctx* ctx);
 
+/* The same in two halves, so that a caller can keep several contexts (batches) in flight on one GPU: the tail of one
+ * batch -- a few long candidates, most of the device idle -- then overlaps the bulk of the next.  topay_optimize ==
+ * topay_optimize_async + topay_synchronize.  Results may be read after topay_synchronize.  (All contexts of a process
+ * share one parameter block in constant memory: contexts in flight together must use identical parameters.) */
+topay_status topay_optimize_async(topay_ctx* ctx);
+topay_status topay_synchronize(topay_ctx* ctx);
+
 /* Batch-level results after topay_optimize: success[b] (0/1), cost[b] (traj_cost), n_pieces[b].
  * Any pointer may be NULL. */
 topay_status topay_get_batch(topay_ctx* ctx, int* success, double* cost, int* n_pieces);

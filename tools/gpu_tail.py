@@ -41,3 +41,17 @@ for lo, hi in ((1, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32)
     m = (N >= lo) & (N <= hi)
     if m.any():
         print(f"N {lo}-{hi}: first start {su[m].min()/1e3:.0f} ms, last start {su[m].max()/1e3:.0f} ms, last end {(su[m]+us[m]).max()/1e3:.0f} ms")
+
+# utilisation timeline: resident trajectories over time (20 bins)
+launched = N > 0
+t0 = su[launched].min()
+s_ = su[launched] - t0
+e_ = s_ + us[launched]
+T = e_.max()
+edges = np.linspace(0, T, 21)
+occ = []
+for i in range(20):
+    a, b_ = edges[i], edges[i + 1]
+    overlap = np.clip(np.minimum(e_, b_) - np.maximum(s_, a), 0, None).sum() / (b_ - a)
+    occ.append(int(round(overlap)))
+print("span ms %.0f; mean resident waves per 5%% time bin:" % (T / 1e3), occ)

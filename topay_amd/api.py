@@ -82,6 +82,8 @@ def load(path=None):
     L.topay_set_init_traj.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
     L.topay_reset.argtypes = [C.c_void_p]
     L.topay_optimize.argtypes = [C.c_void_p]
+    L.topay_optimize_async.argtypes = [C.c_void_p]
+    L.topay_synchronize.argtypes = [C.c_void_p]
     L.topay_get_batch.argtypes = [C.c_void_p, c_ip, c_dp, c_ip]
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
@@ -176,6 +178,19 @@ class MomaTrajOptBatch:
     # -- optimizeTraj lines 359-497; returns the per-candidate bool of the reference
     def optimize(self):
         _chk(self.L, self.L.topay_optimize(self.h))
+        succ = np.zeros(self.batch, dtype=np.int32)
+        cost = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_get_batch(self.h, _ip(succ), _dp(cost), None))
+        self.traj_cost = cost
+        return succ.astype(bool)
+
+    def optimize_async(self):
+        """Issue the solve without waiting (several contexts may be in flight on one GPU); pair with finish()."""
+        _chk(self.L, self.L.topay_optimize_async(self.h))
+
+    def finish(self):
+        """Wait for optimize_async and fetch the per-candidate results, like optimize()."""
+        _chk(self.L, self.L.topay_synchronize(self.h))
         succ = np.zeros(self.batch, dtype=np.int32)
         cost = np.zeros(self.batch)
         _chk(self.L, self.L.topay_get_batch(self.h, _ip(succ), _dp(cost), None))

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -217,6 +218,10 @@ struct DevBuf {
 // trajectories on the highest priority: their workgroups are dispatched first, which is what the tail needs.
 static const int kBucketMaxN[TOPAY_NBUCKET] = {7, 10, 13, 16, 21, 26, 32};
 static const int kBucketPrio[TOPAY_NBUCKET] = {+1, +1, +1, 0, -1, -1, -1};  // -1 greatest ... +1 least
+#define TOPAY_MAX_DEVICES 16
+static hipStream_t g_bucket_streams[TOPAY_MAX_DEVICES][TOPAY_NBUCKET] = {};
+static std::mutex g_bucket_mutex;
+
 struct topay_ctx {
   int device = 0;
   topay_params_t hp;
@@ -237,6 +242,7 @@ struct topay_ctx {
   hipStream_t bstream[NBUCKET] = {nullptr};
   hipEvent_t bevent[NBUCKET] = {nullptr};
   hipEvent_t bstart = nullptr;
+  bool pending = false;  // a topay_optimize_async has been issued and not yet waited for
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
@@ -395,8 +401,18 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
   HIPCHK(hipEventCreate(&c->bstart));
+  // The bucket streams are shared by every context of the process on this device: a second batch issued while the
+  // first is still running queues each of its buckets behind the same bucket of the first, so its short-trajectory
+  // buckets start as soon as the first batch's have drained and fill the SIMDs the first batch's tail leaves idle.
+  const int dev_slot = device % TOPAY_MAX_DEVICES;
+  {
+    std::lock_guard<std::mutex> lk(g_bucket_mutex);
+    for (int k = 0; k < topay_ctx::NBUCKET; k++)
+      if (!g_bucket_streams[dev_slot][k])
+        HIPCHK(hipStreamCreateWithPriority(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking, kBucketPrio[k]));
+  }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    HIPCHK(hipStreamCreateWithPriority(&c->bstream[k], hipStreamNonBlocking, kBucketPrio[k]));
+    c->bstream[k] = g_bucket_streams[dev_slot][k];
     HIPCHK(hipEventCreate(&c->bevent[k]));
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
@@ -415,7 +431,6 @@ void topay_destroy(topay_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    if (c->bstream[k]) (void)hipStreamDestroy(c->bstream[k]);
     if (c->bevent[k]) (void)hipEventDestroy(c->bevent[k]);
   }
   if (c->bstart) (void)hipEventDestroy(c->bstart);
@@ -646,7 +661,7 @@ static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args...
 
 extern "C" {
 
-topay_status topay_optimize(topay_ctx* c) {
+topay_status topay_optimize_async(topay_ctx* c) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -656,12 +671,28 @@ topay_status topay_optimize(topay_ctx* c) {
   topay_status s = launch_classes(c, k_solve1, k_solve2, k_solve3);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  c->last_ms = ms;
-  c->solved = true;
+  c->pending = true;
   return TOPAY_OK;
+}
+
+topay_status topay_synchronize(topay_ctx* c) {
+  if (!c) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->pending) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    c->solved = true;
+    c->pending = false;
+  }
+  return TOPAY_OK;
+}
+
+topay_status topay_optimize(topay_ctx* c) {
+  topay_status s = topay_optimize_async(c);
+  if (s != TOPAY_OK) return s;
+  return topay_synchronize(c);
 }
 
 topay_status topay_get_nmax(topay_ctx* c, int* nmax, int* Nmax) {
