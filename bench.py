@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
+                    help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
+                         "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
+    ap.add_argument("--hires-size", type=float, default=50.0)
     ap.add_argument("--inflight", type=int, default=2, help="batches (contexts) in flight per GPU; 1 = strictly serial steps")
     args = ap.parse_args()
 
@@ -92,7 +96,19 @@ def main():
     # ---- synthetic inputs (CPU harness, untimed): S scenarios of this rank, one map each
     S, Ccand = args.scenarios, args.candidates
     t0 = time.time()
-    tb = wl.TablesBatch(S, Ccand, base_seed=42 + rank * 100000, nthreads=0)
+    hires = args.workload == "hires"
+    if hires:
+        # BASELINE config 5: one high-resolution map, many scenarios on it (the 3-D ESDF no longer fits L2 + Infinity Cache)
+        class _OneMap:  # same fields as TablesBatch
+            pass
+        tb = _OneMap()
+        hw, tb.lens, tb.paths, tb.scen = wl.cuboids_batch(S, Ccand, map_seed=42 + rank, base_seed=42 + rank * 100000,
+                                                          size_xy=args.hires_size, size_z=1.6, res=0.02, cloud_res=0.02)
+        tb.scenarios = [0]
+        tb.world = lambda s_: hw
+        tb_map_of = np.zeros(len(tb.lens), dtype=np.int32)
+    else:
+        tb = wl.TablesBatch(S, Ccand, base_seed=42 + rank * 100000, nthreads=0)
     B = len(tb.lens)
     # `--inflight` contexts hold the same batch (in a sweep they would hold consecutive batches): step i runs on context
     # i mod inflight, so the tail of one step -- a few long candidates, most SIMDs idle -- overlaps the bulk of the next.
@@ -105,7 +121,7 @@ def main():
             w = tb.world(s)
             o_.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, map_id=k)
             slot[s] = k
-        map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+        map_ids = tb_map_of if hires else np.array([slot[s] for s in tb.scen], dtype=np.int32)
         o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)   # raw init paths + maps now resident in HBM
         opts.append(o_)
     opt = opts[0]
@@ -176,7 +192,7 @@ def main():
         import glob
 
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if cands and S == 1024 and Ccand == 8:
+        if cands and S == 1024 and Ccand == 8 and not hires:
             tj = json.load(open(cands[-1]))
             traffic = float(tj["traffic_bytes"])
             traffic_src = os.path.relpath(cands[-1], ROOT)
@@ -196,9 +212,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"benchmark_tables batch (BASELINE configs[3] per-GPU share: 8192 scenarios / 8 GPUs): {S} "
-                        f"scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, tables map 20x20x1.6 m @0.1 m "
-                        "regenerated per scenario, both stages + ALM to convergence",
+            "workload": (f"BASELINE configs[4] high-resolution ESDF: ONE cuboids map {args.hires_size:g}x{args.hires_size:g}x1.6 m "
+                         f"@0.02 m ({tb.world(0).esdf3d.nbytes / 1e9:.2f} GB 3-D ESDF), {S} scenarios/GPU x {Ccand} candidates = {B} "
+                         "trajectories/GPU, both stages + ALM to convergence") if hires else
+                        (f"benchmark_tables batch (BASELINE configs[3] per-GPU share: 8192 scenarios / 8 GPUs): {S} "
+                         f"scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, tables map 20x20x1.6 m @0.1 m "
+                         "regenerated per scenario, both stages + ALM to convergence"),
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
             "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
@@ -217,7 +236,7 @@ def main():
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not hires:
         # CPU baseline: the oracle (a C++ port of the reference path; the reference itself needs Eigen/ROS/Boost and
         # cannot be built here) on the host cores of this box.  One pool of worker threads, one trajectory per task,
         # every trajectory against its own scenario's map; bounded sample = the first `cpu_sample` trajectories.

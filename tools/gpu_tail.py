@@ -55,3 +55,4 @@ for i in range(20):
     overlap = np.clip(np.minimum(e_, b_) - np.maximum(s_, a), 0, None).sum() / (b_ - a)
     occ.append(int(round(overlap)))
 print("span ms %.0f; mean resident waves per 5%% time bin:" % (T / 1e3), occ)
+np.savez("gpurun_out/tail_data.npz", N=N, lens=tb.lens, evals=ev, ok=ok, us=us, start=su, st=st, scen=tb.scen)
