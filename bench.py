@@ -178,6 +178,7 @@ def main():
         total_traj = float(B)
 
     stats = opt.stats()
+    gate = opt.check_feasible()          # printConstraintsSituations over the batch (untimed; a few milliseconds)
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
     # overlapping, those spans overlap too, so the average wall time per step is used instead (never smaller than the
@@ -221,6 +222,7 @@ def main():
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
             "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
+            "gate_pass_fraction_of_successes": float(gate[ok].mean()) if ok.any() else 0.0,
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
             "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),

@@ -210,8 +210,15 @@ topay_status topay_eval(topay_ctx* ctx, int stage, int i, const double* x, const
 topay_status topay_eval_batch(topay_ctx* ctx, int stage, int repeats, double* f /* batch */);
 topay_status topay_get_nmax(topay_ctx* ctx, int* nmax, int* Nmax);
 
-/* == printConstraintsSituations (moma_traj_opt.h:1052-1204) for every candidate: feasible[b] 0/1. */
+/* == printConstraintsSituations (moma_traj_opt.h:1052-1204), the gate the planner applies to every optimised candidate
+ * (planner.cpp:878-880), for every candidate of the batch after topay_optimize: feasible[b] 0/1.  The trajectory is
+ * sampled every 0.01 s through MomaTraj::getState (moma_traj_opt.h:26-137).
+ * topay_feasibility_report also returns checkFeasible's verdict (948-1050: additionally requires the sphere clearances)
+ * and the extreme values the verdicts are made from, 38 doubles per candidate:
+ *   |v| |a| |omega| |domega| maxima, |q| max[7], |dq| max[7], |d2q| max[7], chassis min distance, sphere min distance[12].
+ * Any output pointer may be NULL. */
 topay_status topay_check_feasible(topay_ctx* ctx, int* feasible);
+topay_status topay_feasibility_report(topay_ctx* ctx, int* feasible, int* strict, double* report /* batch x 38 */);
 
 /* Debug / parity tooling: record the cost f of every evaluation made by the next topay_optimize
  * (at most `cap` per candidate, 0 switches it off); topay_get_trace copies candidate i's `cap` values. */

@@ -175,6 +175,18 @@ class Oracle:
         self.L.orc_get_traj(self.h, _dp(d), _dp(c), _dp(k))
         return d, c.reshape(N, 9, 6), k.reshape(N + 1, 2)
 
+    def check_feasible(self):
+        """printConstraintsSituations / checkFeasible on the held trajectory -> (feasible, strict, report[38])."""
+        rep = np.zeros(38)
+        st = C.c_int(0)
+        f = self.L.orc_check_feasible(self.h, _dp(rep), C.byref(st))
+        return bool(f), bool(st.value), rep
+
+    def traj_state(self, t):
+        s = np.zeros(10)
+        self.L.orc_traj_state(self.h, C.c_double(t), _dp(s))
+        return s
+
 
 def optimize_batch(m, path_len, paths, bvel=None, bacc=None, nthreads=1, alm_max_outer=0, maxN=0):
     """Thread-pool batch solve (cpu_baseline leg). Returns dict with success, cost, n_pieces, stats, seconds."""

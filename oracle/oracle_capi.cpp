@@ -140,6 +140,19 @@ double orc_traj_cost(void* hh) { return ((OracleHandle*)hh)->opt.traj_cost; }
 void orc_get_traj(void* hh, double* durations, double* coeffs, double* knots_xy) {
   ((OracleHandle*)hh)->opt.getTraj(durations, coeffs, knots_xy);
 }
+// feasibility gate on the trajectory currently held (printConstraintsSituations; *strict = checkFeasible)
+int orc_check_feasible(void* hh, double* report38, int* strict) {
+  bool st = false;
+  const bool f = ((OracleHandle*)hh)->opt.checkSituations(report38, &st);
+  if (strict) *strict = st ? 1 : 0;
+  return f ? 1 : 0;
+}
+// MomaTraj::getState(t) of the trajectory currently held (10 values)
+void orc_traj_state(void* hh, double t, double* state10) {
+  auto& o = ((OracleHandle*)hh)->opt;
+  const auto seq = o.carSeq();
+  o.trajState(seq, t, state10);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Batch solve with a thread pool: the CPU baseline leg (one trajectory per task, the analogue of

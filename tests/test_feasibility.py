@@ -1,0 +1,99 @@
+"""Feasibility gate (printConstraintsSituations / checkFeasible, moma_traj_opt.h:948-1204) and the MomaTraj playback
+it samples through (moma_traj_opt.h:26-137): oracle self-consistency, kernel sources (CPU lane emulator) vs oracle,
+and — on the GPU — HIP vs emulator (bit-identical) and vs oracle."""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, set_map
+from oracle import oracle as orc
+from topay_amd import api
+from topay_amd.harness import workload as wl
+
+
+def _oracle_gate(m, path, x, alm):
+    o = orc.Oracle(m)
+    o.set_init_traj(path)
+    o.set_alm(alm[:2], alm[2:])
+    o.eval(2, x)                      # loads the spline of x into the oracle
+    return o, o.check_feasible()
+
+
+def test_oracle_playback_is_consistent(cuboids_small):
+    """MomaTraj::getState at t = 0 / T reproduces the start state / the Simpson-integrated end knot of getTraj, joints
+    and yaw follow the polynomial, and the report's extremes bound the sampled values."""
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    path = cs["paths"][cs["offs"][1]:cs["offs"][2]]
+    o.set_init_traj(path)
+    assert o.optimize()
+    d, c, kn = o.get_traj()
+    s0, sT = o.traj_state(0.0), o.traj_state(d.sum())
+    assert np.allclose(s0[:3], path[0][:3], atol=1e-12) and np.allclose(s0[3:], path[0][3:], atol=1e-9)
+    assert np.linalg.norm(sT[:2] - kn[-1]) < 1e-4      # 0.025 s panels vs the optimiser's T/12 panels
+    assert np.allclose(sT[3:], path[-1][3:], atol=1e-6)
+    f, st, rep = o.check_feasible()
+    assert abs(rep[0]) <= 1.01 * 1.0 + 0.05 and rep[25] > 0.3 and (rep[26:] > 0).all()
+    mid = o.traj_state(0.37 * d.sum())
+    assert (np.abs(mid[3:]) <= np.abs(rep[4:11]) + 1e-12).all()
+
+
+def test_gate_kernel_matches_oracle_on_cpu(cuboids_small):
+    cs = cuboids_small
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    lens, paths = cs["lens"][:4], cs["paths"][:cs["offs"][4]]
+    emu.optimizeTraj(lens, paths)
+    f, st, rep = emu.check_feasible(report=True)
+    assert (emu.check_feasible() == f).all()
+    alm = emu.alm_state()
+    for b in range(4):
+        _, (fo, so, ro) = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
+        assert fo == f[b] and so == st[b]
+        # extremes: 1e-10 relative (libm vs deterministic sin/cos, scan vs running sum in car_seq)
+        assert np.allclose(np.abs(ro), rep[b], rtol=1e-10, atol=1e-12)
+
+
+def test_gate_rejects_a_too_fast_trajectory(cuboids_small):
+    """Tighten the limits instead of editing the trajectory: with max_v scaled down the same candidate must fail on
+    the velocity test and only there (the gate reads the limits from the parameter block)."""
+    cs = cuboids_small
+    lens, paths = cs["lens"][:1], cs["paths"][:cs["offs"][1]]
+    p = api.default_params()
+    emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    emu.optimizeTraj(lens, paths)
+    f, st, rep = emu.check_feasible(report=True)
+    assert f[0] and rep[0, 0] > 0.5
+    p.s2_lbfgs.max_iterations = 1
+    p.alm_max_outer = 1                 # stop early: the half-optimised trajectory still violates its limits
+    emu2 = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(emu2, cs["world"])
+    emu2.optimizeTraj(lens, paths)
+    f2, st2, rep2 = emu2.check_feasible(report=True)
+    lim = np.array([1.0, 0.8, 1.25, 1.0])
+    assert f2[0] == bool((rep2[0, :4] <= 1.01 * lim).all() and (rep2[0, 4:11] <= 1.01 * np.array([3.1, 2.26, 3.1, 2.355, 3.1, 2.23, 6.28])).all()
+                         and (rep2[0, 11:18] <= 1.01 * 2.35).all() and (rep2[0, 18:25] <= 1.01 * 6.28).all() and rep2[0, 25] >= 0.99 * 0.4)
+
+
+@pytest.mark.gpu
+def test_gate_on_gpu_matches_emulator_and_oracle():
+    world, start, goal, lens, paths = wl.tables_scenario(3, 8)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    res = {}
+    for name, lib in (("gpu", None), ("emu", EMU_LIB)):
+        opt = api.MomaTrajOptBatch(device=0, lib_path=lib)
+        set_map(opt, world)
+        nb = len(lens) if name == "gpu" else 2
+        opt.optimizeTraj(lens[:nb], paths[:offs[nb]])
+        res[name] = (opt, opt.check_feasible(report=True))
+    (fg, sg, rg), (fe, se, re_) = res["gpu"][1], res["emu"][1]
+    assert (fg[:2] == fe).all() and (sg[:2] == se).all() and (rg[:2] == re_).all()   # bit-identical to the CPU execution
+    m = orc.MapView(world.origin, world.res, world.dims, world.min_b, world.max_b, world.esdf2d, world.esdf3d)
+    gpu = res["gpu"][0]
+    alm = gpu.alm_state()
+    for b in range(len(lens)):
+        if not np.isfinite(rg[b]).all():
+            continue
+        _, (fo, so, ro) = _oracle_gate(m, paths[offs[b]:offs[b + 1]], gpu.get_x(b), alm[b])
+        assert fo == fg[b] and so == sg[b]
+        assert np.allclose(np.abs(ro), rg[b], rtol=1e-9, atol=1e-11)

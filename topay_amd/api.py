@@ -88,6 +88,8 @@ def load(path=None):
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
+    L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
+    L.topay_feasibility_report.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
     L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp]
     L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -224,6 +226,18 @@ class MomaTrajOptBatch:
         s = np.zeros(self.batch * 8, dtype=np.int32)
         _chk(self.L, self.L.topay_get_stats(self.h, _ip(s)))
         return s.reshape(self.batch, 8)
+
+    def check_feasible(self, report=False):
+        """printConstraintsSituations for every candidate (bool array); with report=True also checkFeasible's verdict
+        and the 38 extreme values per candidate."""
+        f = np.zeros(self.batch, dtype=np.int32)
+        if not report:
+            _chk(self.L, self.L.topay_check_feasible(self.h, _ip(f)))
+            return f.astype(bool)
+        st = np.zeros(self.batch, dtype=np.int32)
+        rep = np.zeros(self.batch * 38)
+        _chk(self.L, self.L.topay_feasibility_report(self.h, _ip(f), _ip(st), _dp(rep)))
+        return f.astype(bool), st.astype(bool), rep.reshape(self.batch, 38)
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

@@ -1,0 +1,253 @@
+// Feasibility gate of a finished trajectory — printConstraintsSituations (planner/include/planner/moma_traj_opt.h:
+// 1052-1204, the check the planner applies to every optimised candidate, planner.cpp:878-880) and checkFeasible
+// (948-1050), with the MomaTraj playback they sample through (moma_traj_opt.h:26-137: car_seq every 0.1 s from
+// Simpson panels of 0.025 s, getState = car_seq entry + one partial Simpson panel).
+//
+// One wavefront per trajectory:
+//   1. car_seq: lanes <-> Simpson panels, wave inclusive scan with a carry across passes, prefix after every panel
+//      kept in HBM scratch (the reference keeps every 4th; the others are free).
+//   2. the sample times t = 0, 0.01, 0.02, ... are the reference's running sum (t += res), produced serially by one
+//      lane so that the number of samples and their values are the reference's.
+//   3. lanes <-> samples: state, velocity, acceleration, the 12 sphere centres, 1 + 12 ESDF values; lane-local
+//      extrema, wave max / min at the end.
+// report[38] = { |v|, |a|, |omega|, |domega| maxima, |q| max[7], |dq| max[7], |d2q| max[7], chassis min distance,
+// sphere min distance[12] }.
+#pragma once
+#include "topay_eval.h"
+
+namespace topay {
+
+struct FeasIO {
+  const double* coef;   // [9][rows], rows = 6N, element d*rows + 6i + k = coefficient of t^k
+  const double* T;      // [N]
+  int N;
+  double x0, y0, th0;   // start_state.head(3)
+  double* cseq;         // scratch [(panels + 1)][2]
+  double* tk;           // scratch [samples]
+  long long cap_panels, cap_samples;
+  double* report;       // [38]
+  int* feasible;        // [2]: printConstraintsSituations, checkFeasible
+};
+
+// PolyTrajectory::locatePieceIdx (minco.hpp:356-374): t becomes the local time
+__device__ __forceinline__ int feas_locate(const double* T, int N, double& t) {
+  int idx;
+  double dur = 0.0;
+  for (idx = 0; idx < N && t > (dur = T[idx]); idx++) t -= dur;
+  if (idx == N) { idx--; t += T[idx]; }
+  return idx;
+}
+// Piece::getPos / getVel / getAcc (minco.hpp:103-150) of dimension d
+__device__ __forceinline__ double feas_pos(const double* c, double t) {
+  double v = 0.0, tn = 1.0;
+#pragma unroll
+  for (int k = 0; k <= 5; k++) { v += tn * c[k]; tn *= t; }
+  return v;
+}
+__device__ __forceinline__ double feas_vel(const double* c, double t) {
+  double v = 0.0, tn = 1.0;
+#pragma unroll
+  for (int k = 1; k <= 5; k++) { v += (double)k * tn * c[k]; tn *= t; }
+  return v;
+}
+__device__ __forceinline__ double feas_acc(const double* c, double t) {
+  double v = 0.0, tn = 1.0;
+#pragma unroll
+  for (int k = 2; k <= 5; k++) { v += (double)((k - 1) * k) * tn * c[k]; tn *= t; }
+  return v;
+}
+// theta and arc-length rate at global time t: (p.x, v.y) of the reference's 2-vectors
+__device__ __forceinline__ void feas_theta_sdot(const FeasIO& F, double t, double& th, double& sd) {
+  const int i = feas_locate(F.T, F.N, t);
+  const int rows = 6 * F.N;
+  th = feas_pos(F.coef + 0 * rows + 6 * i, t);
+  sd = feas_vel(F.coef + 1 * rows + 6 * i, t);
+}
+__device__ __forceinline__ void feas_simpson(const FeasIO& F, double ta, double tb, double tc, double w6, double& ix,
+                                             double& iy) {
+  double th1, sd1, th2, sd2, th3, sd3, s1, c1, s2, c2, s3, c3;
+  feas_theta_sdot(F, ta, th1, sd1);
+  feas_theta_sdot(F, tb, th2, sd2);
+  feas_theta_sdot(F, tc, th3, sd3);
+  det_sincos(th1, &s1, &c1);
+  det_sincos(th2, &s2, &c2);
+  det_sincos(th3, &s3, &c3);
+  ix = w6 * (sd1 * c1 + 4.0 * sd2 * c2 + sd3 * c3);
+  iy = w6 * (sd1 * s1 + 4.0 * sd2 * s2 + sd3 * s3);
+}
+// value-only lookups: out of the map -> 1e10 (grid_map.h:256-362)
+__device__ __forceinline__ double feas_dist2d(const DevMap& M, double px, double py) {
+  const bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4);
+  double d = 0.0, gx, gy;
+  if (in) esdf2d_query(M, px, py, d, gx, gy);
+  return in ? d : 1.0e+10;
+}
+__device__ __forceinline__ double feas_dist3d(const DevMap& M, double px, double py, double pz) {
+  const bool in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || pz < M.min_b[2] + 1e-4 ||
+                    px > M.max_b[0] - 1e-4 || py > M.max_b[1] - 1e-4 || pz > M.max_b[2] - 1e-4);
+  double d, gx, gy, gz;
+  esdf3d_query(M, px, py, pz, d, gx, gy, gz);
+  return in ? d : 1.0e+10;
+}
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+
+__device__ __forceinline__ void feasibility_gate(const FeasIO& F, const TOPAY_GLB DevMap* mp) {
+  const DevParams& P = g_P;
+  const int lane = threadIdx.x & 63;
+  const int N = F.N, rows = 6 * N;
+  const DevMap M = load_map(mp);
+  double Ttot = 0.0;
+  for (int i = 0; i < N; i++) Ttot += F.T[i];  // getTotalDuration (minco.hpp:304-313)
+  if (!(Ttot > 0.0 && Ttot < 1.0e4)) {         // no trajectory (failed solve left NaNs): infeasible, nothing to sample
+    if (lane == 0) {
+      for (int k = 0; k < 38; k++) F.report[k] = 0.0 / 0.0;
+      F.feasible[0] = 0;
+      F.feasible[1] = 0;
+    }
+    return;
+  }
+
+  // ---- 1. car_seq
+  const double seq_res = 0.1;
+  const int approx_res = 4;
+  const double h = seq_res / approx_res, hh = h / 2.0, h6 = h / 6.0;
+  long long num = (long long)floor(Ttot / h);
+  if (num > F.cap_panels) num = F.cap_panels;
+  if (lane == 0) { F.cseq[0] = F.x0; F.cseq[1] = F.y0; }
+  double carryx = 0.0, carryy = 0.0;
+  for (long long p0 = 0; p0 < num; p0 += 64) {
+    const long long i = p0 + lane;
+    double ix = 0.0, iy = 0.0;
+    if (i < num) {
+      // p1 of panel i is the reference's p3 of panel i-1, i.e. evaluated at (i-1)*h + h
+      const double ta = i == 0 ? 0.0 : (double)(i - 1) * h + h;
+      feas_simpson(F, ta, (double)i * h + hh, (double)i * h + h, h6, ix, iy);
+    }
+    const double sx = wave_incl_scan(ix, lane), sy = wave_incl_scan(iy, lane);
+    if (i < num) {
+      F.cseq[2 * (i + 1)] = F.x0 + (carryx + sx);
+      F.cseq[2 * (i + 1) + 1] = F.y0 + (carryy + sy);
+    }
+    carryx += __shfl(sx, 63);
+    carryy += __shfl(sy, 63);
+  }
+  // ---- 2. sample times (t += res from 0 while t < T)
+  long long nsamp = 0;
+  if (lane == 0) {
+    const double res = 0.01;
+    long long k = 0;
+    for (double t = 0.0; t < Ttot && k < F.cap_samples; t += res) F.tk[k++] = t;
+    nsamp = k;
+  }
+  __syncthreads();  // cseq / tk stores become visible to the other lanes
+  nsamp = (long long)__shfl((int)nsamp, 0);
+
+  // ---- 3. samples
+  double mv = 0, ma = 0, mw = 0, mdw = 0, mq[7], mdq[7], md2q[7], mind = 1.0e+10, minm[TOPAY_NSPH];
+#pragma unroll
+  for (int q = 0; q < 7; q++) { mq[q] = 0.0; mdq[q] = 0.0; md2q[q] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) minm[k] = 1.0e+10;
+  for (long long s0 = 0; s0 < nsamp; s0 += 64) {
+    const long long s = s0 + lane;
+    if (s < nsamp) {
+      const double tg = F.tk[s];
+      // getState (moma_traj_opt.h:113-137); t is already inside [0, T)
+      const int index = (int)floor(tg / seq_res);
+      const double floor_t = index * seq_res, diff_t = tg - floor_t;
+      long long pidx = (long long)index * approx_res;
+      if (pidx > num) pidx = num;
+      double ix, iy;
+      feas_simpson(F, floor_t, floor_t + diff_t / 2.0, tg, diff_t / 6.0, ix, iy);
+      const double px = F.cseq[2 * pidx] + ix, py = F.cseq[2 * pidx + 1] + iy;
+      double tl = tg;
+      const int i = feas_locate(F.T, N, tl);
+      double pos[10], sq[7], cq[7];
+      pos[0] = px; pos[1] = py;
+      pos[2] = feas_pos(F.coef + 0 * rows + 6 * i, tl);
+      const double v_th = feas_vel(F.coef + 0 * rows + 6 * i, tl), v_s = feas_vel(F.coef + 1 * rows + 6 * i, tl);
+      const double a_th = feas_acc(F.coef + 0 * rows + 6 * i, tl), a_s = feas_acc(F.coef + 1 * rows + 6 * i, tl);
+      mv = fmax(mv, fabs(v_s)); ma = fmax(ma, fabs(a_s)); mw = fmax(mw, fabs(v_th)); mdw = fmax(mdw, fabs(a_th));
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const double* c = F.coef + (2 + q) * rows + 6 * i;
+        pos[3 + q] = feas_pos(c, tl);
+        mq[q] = fmax(mq[q], fabs(pos[3 + q]));
+        mdq[q] = fmax(mdq[q], fabs(feas_vel(c, tl)));
+        md2q[q] = fmax(md2q[q], fabs(feas_acc(c, tl)));
+        det_sincos(pos[3 + q], &sq[q], &cq[q]);
+      }
+      mind = fmin(mind, feas_dist2d(M, px, py));
+      // sphere centres — moma_param.h:203-247 (same walk as manipulator_block)
+      double sth, cth;
+      det_sincos(pos[2], &sth, &cth);
+      double A[9];
+      {
+        const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            A[a * 3 + b] = Rz[a * 3 + 0] * P.relR[0 * 3 + b] + Rz[a * 3 + 1] * P.relR[1 * 3 + b] + Rz[a * 3 + 2] * P.relR[2 * 3 + b];
+      }
+      const double p0x = pos[0] + (cth * P.relT[0] - sth * P.relT[1]);
+      const double p0y = pos[1] + (sth * P.relT[0] + cth * P.relT[1]);
+      const double p0z = P.chassis_height + P.relT[2];
+      double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+      double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+      int sidx = 0;
+#pragma unroll
+      for (int li = 0; li < 8; li++) {
+        const int cnt = (li % 2 == 0) ? 2 : 1;
+#pragma unroll
+        for (int c = 0; c < cnt; c++) {
+          const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
+          const double wx = p0x + fma(A[2], lz, fma(A[1], ly, A[0] * lx));
+          const double wy = p0y + fma(A[5], lz, fma(A[4], ly, A[3] * lx));
+          const double wz = p0z + fma(A[8], lz, fma(A[7], ly, A[6] * lx));
+          minm[sidx] = fmin(minm[sidx], feas_dist3d(M, wx, wy, wz));
+          sidx++;
+        }
+        q0 = fma(R[2], P.colli_length[li], q0);
+        q1 = fma(R[5], P.colli_length[li], q1);
+        q2 = fma(R[8], P.colli_length[li], q2);
+        if (li == 7) break;
+        joint_rotate(R, li, cq[li], sq[li]);
+      }
+    }
+  }
+  // ---- verdicts
+  mv = wave_max(mv); ma = wave_max(ma); mw = wave_max(mw); mdw = wave_max(mdw);
+  mind = wave_min(mind);
+  bool feasible = true;
+  if (mv > 1.01 * P.max_v) feasible = false;
+  if (ma > 1.01 * P.max_a) feasible = false;
+  if (mw > 1.01 * P.max_w) feasible = false;
+  if (mdw > 1.01 * P.max_dw) feasible = false;
+#pragma unroll
+  for (int q = 0; q < 7; q++) {
+    mq[q] = wave_max(mq[q]); mdq[q] = wave_max(mdq[q]); md2q[q] = wave_max(md2q[q]);
+    if (mq[q] > 1.01 * P.joint_pos_limit_max[q]) feasible = false;
+    if (mdq[q] > 1.01 * P.joint_vel_limit[q]) feasible = false;
+    if (md2q[q] > 1.01 * P.joint_acc_limit[q]) feasible = false;
+  }
+  if (mind < 0.99 * P.chassis_colli_radius) feasible = false;
+  bool strict = feasible;
+#pragma unroll
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    minm[k] = wave_min(minm[k]);
+    if (minm[k] < 0.99 * P.sph_r[k]) strict = false;
+  }
+  if (lane == 0) {
+    F.report[0] = mv; F.report[1] = ma; F.report[2] = mw; F.report[3] = mdw;
+#pragma unroll
+    for (int q = 0; q < 7; q++) { F.report[4 + q] = mq[q]; F.report[11 + q] = mdq[q]; F.report[18 + q] = md2q[q]; }
+    F.report[25] = mind;
+#pragma unroll
+    for (int k = 0; k < TOPAY_NSPH; k++) F.report[26 + k] = minm[k];
+    F.feasible[0] = feasible ? 1 : 0;
+    F.feasible[1] = strict ? 1 : 0;
+  }
+}
+
+}  // namespace topay

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "topay_solve.h"
+#include "topay_feas.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
 // One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
@@ -164,6 +165,30 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval3(DevBatch Bt, c
   eval_body<3>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 
+// feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
+__global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
+                                                 long long cap_samples, double* report, int* flags) {
+  const int b = blockIdx.x;
+  const int N = Bt.N[b];
+  if (N <= 0) {
+    if (threadIdx.x == 0) { flags[2 * b] = 0; flags[2 * b + 1] = 0; }
+    return;
+  }
+  FeasIO F;
+  F.coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
+  F.T = Bt.T + (size_t)b * Bt.Nmax;
+  F.N = N;
+  F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
+  F.th0 = Bt.head[(size_t)b * 27];
+  F.cseq = cseq + (size_t)b * 2 * (cap_panels + 1);
+  F.tk = tk + (size_t)b * cap_samples;
+  F.cap_panels = cap_panels; F.cap_samples = cap_samples;
+  F.report = report + (size_t)b * 38;
+  F.feasible = flags + 2 * b;
+  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
+  feasibility_gate(F, mp);
+}
+
 // test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
 __global__ void k_math(const double* a, const double* b, double* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,7 +271,7 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags;
   int trace_cap = 0;
   DevBatch db;
   bool have_traj = false, solved = false;
@@ -427,7 +452,7 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus};
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
@@ -846,9 +871,42 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
 }
 
 topay_status topay_check_feasible(topay_ctx* c, int* feasible) {
-  (void)c; (void)feasible;
-  set_err("topay_check_feasible: not built yet (SURVEY.md section 8f rank 1)");
-  return TOPAY_ERR_UNSUPPORTED;
+  return topay_feasibility_report(c, feasible, nullptr, nullptr);
+}
+
+topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, double* report) {
+  if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  const int B = c->B;
+  // scratch is sized from the longest returned trajectory
+  std::vector<double> hT((size_t)B * c->Nmax);
+  HIPCHK(hipMemcpy(hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  double tmax = 0.0;
+  for (int b = 0; b < B; b++) {
+    double t = 0.0;
+    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)b * c->Nmax + i];
+    if (t > 0.0 && t < 1.0e4 && t > tmax) tmax = t;
+  }
+  const long long cap_panels = (long long)(tmax / 0.025) + 4, cap_samples = (long long)(tmax / 0.01) + 16;
+  topay_status s;
+  if ((s = c->feas_cseq.ensure((size_t)B * 2 * (cap_panels + 1) * 8)) != TOPAY_OK) return s;
+  if ((s = c->feas_tk.ensure((size_t)B * cap_samples * 8)) != TOPAY_OK) return s;
+  if ((s = c->feas_report.ensure((size_t)B * 38 * 8)) != TOPAY_OK) return s;
+  if ((s = c->feas_flags.ensure((size_t)B * 2 * 4)) != TOPAY_OK) return s;
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  hipLaunchKernelGGL(k_feasible, dim3(B), dim3(64), 0, c->stream, c->db, (const DevMap*)c->dmaps.p, c->feas_cseq.as<double>(),
+                     c->feas_tk.as<double>(), cap_panels, cap_samples, c->feas_report.as<double>(), c->feas_flags.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<int> fl((size_t)B * 2);
+  HIPCHK(hipMemcpy(fl.data(), c->feas_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; b++) {
+    if (feasible) feasible[b] = fl[2 * b];
+    if (strict) strict[b] = fl[2 * b + 1];
+  }
+  if (report) HIPCHK(hipMemcpy(report, c->feas_report.p, (size_t)B * 38 * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
 }
 
 // Debug / parity tooling: record f of every evaluation of the next topay_optimize (cap per candidate; 0 = off).
