@@ -8,6 +8,7 @@ import pytest
 from conftest import EMU_LIB, set_map
 from oracle import oracle as orc
 from topay_amd import api
+from topay_amd.harness import workload as wl
 
 
 @pytest.fixture(scope="module")
@@ -144,3 +145,44 @@ def test_three_rows_per_lane_class_and_too_long_paths(cuboids_small):
         opt.get_x(2)
     r = opt.getTraj(2)
     assert r["success"] is False and len(r["durations"]) == 0
+
+
+def test_edge_case_inputs_follow_the_oracle():
+    """Degenerate inputs the reference accepts: a two-state hop, a rotation in place, identical start and goal (no inner
+    point: one piece, stage 1 stops with an error code and the candidate is reported failed) and a 24 m path.  Piece
+    counts, the packed initial guess, the stage-1 counters (not chaotic) and the success flags agree with the oracle."""
+    w = wl.World(wl.CUBOIDS, seed=42)
+    m = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
+    ok, s, g = w.sample_scenario(42)
+    assert ok
+    hop = s.copy(); hop[0] += 0.6; hop[1] += 0.2
+    turn = s.copy(); turn[2] += 1.5
+    a, b = s.copy(), s.copy()
+    a[0] = a[1] = -8.5
+    b[0] = b[1] = 8.5
+    far = np.stack([a + (b - a) * t for t in np.linspace(0, 1, 40)])
+    far[:, 2] = np.arctan2(1.0, 1.0)
+    cases = [np.stack([s, hop]), np.stack([s, turn]), np.stack([s, s.copy()])]
+    lens = np.array([len(c) for c in cases], dtype=np.int32)
+    paths = np.concatenate(cases)
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, w)
+    okv = emu.optimizeTraj(lens, paths)
+    st = emu.stats()
+    Ns = emu.n_pieces()
+    for k, c in enumerate(cases):
+        o = orc.Oracle(m)
+        o.set_init_traj(c)
+        r = o.optimize()
+        so = o.stats()
+        assert Ns[k] == o.N
+        assert list(st[k, :3]) == [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"]]
+        assert bool(okv[k]) == bool(r)
+    assert okv[0] and okv[1] and not okv[2] and Ns[2] == 1 and np.isnan(emu.traj_cost[2])
+    # the long path: initialisation only (a 23-piece solve takes minutes in the lane emulator; the GPU tests solve such)
+    emu.set_init_traj(np.array([len(far)], dtype=np.int32), far)
+    o = orc.Oracle(m)
+    o.set_init_traj(far)
+    assert emu.n_pieces()[0] == o.N == 23
+    assert np.allclose(emu.get_x(0), o.get_x(), rtol=0, atol=1e-12)
+    w.close()
