@@ -191,6 +191,10 @@ topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
  * device clock (only differences are meaningful).  Either pointer may be NULL. */
 topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
 
+/* Total duration of every candidate's returned trajectory (MomaTraj::getTotalDuration): the quantity the planner ranks
+ * the successful candidates of a scenario by (planner.cpp:999-1010). */
+topay_status topay_get_total_durations(topay_ctx* ctx, double* total /* batch */);
+
 /* ALM state (alm_lambda[2], alm_rho[2]) every candidate finished with; traj_cost is the stage-2 cost at the returned x
  * with this state (moma_traj_opt.cpp:398-401, 456-459). */
 topay_status topay_get_alm(topay_ctx* ctx, double* alm /* batch x 4: lambda0, lambda1, rho0, rho1 */);

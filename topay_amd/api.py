@@ -88,6 +88,7 @@ def load(path=None):
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
+    L.topay_get_total_durations.argtypes = [C.c_void_p, c_dp]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
     L.topay_feasibility_report.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
     L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp]
@@ -238,6 +239,12 @@ class MomaTrajOptBatch:
         rep = np.zeros(self.batch * 38)
         _chk(self.L, self.L.topay_feasibility_report(self.h, _ip(f), _ip(st), _dp(rep)))
         return f.astype(bool), st.astype(bool), rep.reshape(self.batch, 38)
+
+    def total_durations(self):
+        """Total duration of every candidate's trajectory (what the planner ranks successful candidates by)."""
+        t = np.zeros(self.batch)
+        _chk(self.L, self.L.topay_get_total_durations(self.h, _dp(t)))
+        return t
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

@@ -744,6 +744,19 @@ topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us) {
   return TOPAY_OK;
 }
 
+topay_status topay_get_total_durations(topay_ctx* c, double* total) {
+  if (!c || !c->have_traj || !total) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<double> hT((size_t)c->B * c->Nmax);
+  HIPCHK(hipMemcpy(hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  for (int b = 0; b < c->B; b++) {
+    double t = 0.0;
+    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)b * c->Nmax + i];  // PolyTrajectory::getTotalDuration, minco.hpp:304-313
+    total[b] = c->hN[b] > 0 ? t : 0.0 / 0.0;
+  }
+  return TOPAY_OK;
+}
+
 topay_status topay_get_alm(topay_ctx* c, double* alm) {
   if (!c || !c->have_traj || !alm) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));

@@ -21,16 +21,36 @@ def shard_range(n_items, rank, world):
 def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durations):
     """Local argmin-by-duration per scenario -> records [n_scen, 6] (float64).
     scen_of_traj[b] is the (global) scenario id of trajectory b; durations[b] its total duration."""
+    scenario_ids = np.asarray(scenario_ids)
+    scen_of_traj = np.asarray(scen_of_traj)
     recs = np.zeros((len(scenario_ids), RECORD_WIDTH))
-    for r, sid in enumerate(scenario_ids):
-        idx = np.nonzero(scen_of_traj == sid)[0]
-        ok = idx[success[idx] > 0]
-        recs[r, 0] = sid
-        if len(ok):
-            best = ok[np.argmin(durations[ok])]
-            recs[r, 1:] = (best - idx[0], 1.0, n_pieces[best], cost[best], durations[best])
-        else:
-            recs[r, 1:] = (-1.0, 0.0, 0.0, np.nan, np.nan)
+    recs[:, 0] = scenario_ids
+    recs[:, 1] = -1.0
+    recs[:, 4:] = np.nan
+    if len(scen_of_traj) == 0:
+        return recs
+    # first trajectory of every scenario (candidate index = position - first) and the best successful one
+    order = np.argsort(scen_of_traj, kind="stable")
+    s_sorted = scen_of_traj[order]
+    first_pos = {}
+    starts = np.nonzero(np.r_[True, s_sorted[1:] != s_sorted[:-1]])[0]
+    for st_ in starts:
+        first_pos[s_sorted[st_]] = order[st_]
+    row_of = {sid: r for r, sid in enumerate(scenario_ids.tolist())}
+    ok = np.nonzero(np.asarray(success) > 0)[0]
+    if len(ok):
+        d_ok = np.asarray(durations)[ok]
+        # lexicographic: scenario, then duration, then trajectory index -> the first entry per scenario is the argmin
+        o2 = np.lexsort((ok, d_ok, scen_of_traj[ok]))
+        so = scen_of_traj[ok][o2]
+        firsts = np.nonzero(np.r_[True, so[1:] != so[:-1]])[0]
+        for f_ in firsts:
+            best = ok[o2[f_]]
+            sid = so[f_]
+            r = row_of.get(int(sid))
+            if r is None:
+                continue
+            recs[r, 1:] = (best - first_pos[sid], 1.0, n_pieces[best], cost[best], durations[best])
     return recs
 
 
