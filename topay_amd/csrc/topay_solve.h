@@ -33,9 +33,34 @@ struct SolveIO {
   int trace_cap;
 };
 
+// Vector operations on the n-element L-BFGS vectors (element e = lane + 64 t, t < EPL, n <= 64 EPL).  Every load of
+// an operation is issued before its arithmetic (clamped index + mask instead of a trip-count loop, whose iterations
+// the compiler serialises): a single wave has nothing else to hide the HBM / L2 latency behind.
+template <int EPL>
+__device__ __forceinline__ void vec_load(glb_cdp a, int n, int lane, double (&v)[EPL]) {
+#pragma unroll
+  for (int t = 0; t < EPL; t++) {
+    const int e = lane + 64 * t;
+    v[t] = a[e < n ? e : n - 1];
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void vec_store(glb_dp a, int n, int lane, const double (&v)[EPL]) {
+#pragma unroll
+  for (int t = 0; t < EPL; t++) {
+    const int e = lane + 64 * t;
+    if (e < n) a[e] = v[t];
+  }
+}
+// sum over the lane's elements in ascending t, then the fixed wave tree (same order as a plain strided loop)
+template <int EPL>
 __device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane) {
+  double av[EPL], bv[EPL];
+  vec_load<EPL>(a, n, lane, av);
+  vec_load<EPL>(b, n, lane, bv);
   double s = 0.0;
-  for (int e = lane; e < n; e += 64) s += a[e] * b[e];
+#pragma unroll
+  for (int t = 0; t < EPL; t++) s += (lane + 64 * t < n) ? av[t] * bv[t] : 0.0;
   return wave_sum(s);
 }
 
@@ -86,11 +111,18 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       fx = f;
       if (lane == 0) pf[0] = fx;
       double gmax = 0.0, xmax = 0.0;
-      for (int e = lane; e < n; e += 64) {
-        const double ge = S.g[e];
-        S.d[e] = -ge;
-        gmax = fmax(gmax, fabs(ge));
-        xmax = fmax(xmax, fabs(S.x[e]));
+      {
+        double gv[EPL], xv[EPL], dv[EPL];
+        vec_load<EPL>(S.g, n, lane, gv);
+        vec_load<EPL>(S.x, n, lane, xv);
+#pragma unroll
+        for (int t = 0; t < EPL; t++) {
+          const bool in = lane + 64 * t < n;
+          dv[t] = -gv[t];
+          gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
+          xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
+        }
+        vec_store<EPL>(S.d, n, lane, dv);
       }
       gmax = wave_max(gmax);
       xmax = wave_max(xmax);
@@ -99,7 +131,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         ret = TOPAY_LBFGS_CONVERGENCE;
         go = GO_RUN_END;
       } else {
-        step = 1.0 / sqrt(vec_dot(S.d, S.d, n, lane));
+        step = 1.0 / sqrt(vec_dot<EPL>(S.d, S.d, n, lane));
         k = 1;
         end = 0;
         bound = 0;
@@ -119,7 +151,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           nu = stp;
           brackt = true;
         } else {
-          const double gs = vec_dot(S.g, S.d, n, lane);
+          const double gs = vec_dot<EPL>(S.g, S.d, n, lane);
           if (gs < dstest) mu = stp;
           else accepted = true;
         }
@@ -137,12 +169,25 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         }
       }
       if (ls == 0) {
-        for (int e = lane; e < n; e += 64) S.x[e] = S.xp[e] + stp * S.d[e];
+        {
+          double pv[EPL], dv[EPL], xv[EPL];
+          vec_load<EPL>(S.xp, n, lane, pv);
+          vec_load<EPL>(S.d, n, lane, dv);
+#pragma unroll
+          for (int t = 0; t < EPL; t++) xv[t] = pv[t] + stp * dv[t];
+          vec_store<EPL>(S.x, n, lane, xv);
+        }
         go = GO_EVAL;
       } else if (ls < 0) {
         // revert to the previous point — lbfgs.hpp:575-582 (fx keeps the last trial value)
         fx = f;
-        for (int e = lane; e < n; e += 64) { S.x[e] = S.xp[e]; S.g[e] = S.gp[e]; }
+        {
+          double pv[EPL], qv[EPL];
+          vec_load<EPL>(S.xp, n, lane, pv);
+          vec_load<EPL>(S.gp, n, lane, qv);
+          vec_store<EPL>(S.x, n, lane, pv);
+          vec_store<EPL>(S.g, n, lane, qv);
+        }
         ret = ls;
         go = GO_RUN_END;
       } else {
@@ -154,7 +199,17 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         if (stage == 2 && k > lp.max_iterations) { ret = TOPAY_LBFGS_CANCELED; fin = true; }
         if (!fin) {
           double gmax = 0.0, xmax = 0.0;
-          for (int e = lane; e < n; e += 64) { gmax = fmax(gmax, fabs(S.g[e])); xmax = fmax(xmax, fabs(S.x[e])); }
+          {
+            double gv[EPL], xv[EPL];
+            vec_load<EPL>(S.g, n, lane, gv);
+            vec_load<EPL>(S.x, n, lane, xv);
+#pragma unroll
+            for (int t = 0; t < EPL; t++) {
+              const bool in = lane + 64 * t < n;
+              gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
+              xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
+            }
+          }
           gmax = wave_max(gmax);
           xmax = wave_max(xmax);
           if (gmax / fmax(1.0, xmax) < lp.g_epsilon) { ret = TOPAY_LBFGS_CONVERGENCE; fin = true; }
@@ -179,12 +234,24 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           glb_dp sE = S.hist_s + (size_t)end * S.nstride;
           glb_dp yE = S.hist_y + (size_t)end * S.nstride;
           double ys = 0.0, yy = 0.0, ss = 0.0, gg = 0.0;
-          for (int e = lane; e < n; e += 64) {
-            const double se = S.x[e] - S.xp[e], ye = S.g[e] - S.gp[e], gpe = S.gp[e];
-            sE[e] = se;
-            yE[e] = ye;
-            ys += ye * se; yy += ye * ye; ss += se * se; gg += gpe * gpe;
-            S.d[e] = -S.g[e];
+          {
+            double xv[EPL], pv[EPL], gv[EPL], qv[EPL], sv[EPL], yv[EPL], dv[EPL];
+            vec_load<EPL>(S.x, n, lane, xv);
+            vec_load<EPL>(S.xp, n, lane, pv);
+            vec_load<EPL>(S.g, n, lane, gv);
+            vec_load<EPL>(S.gp, n, lane, qv);
+#pragma unroll
+            for (int t = 0; t < EPL; t++) {
+              const bool in = lane + 64 * t < n;
+              const double se = xv[t] - pv[t], ye = gv[t] - qv[t], gpe = qv[t];
+              sv[t] = se;
+              yv[t] = ye;
+              ys += in ? ye * se : 0.0; yy += in ? ye * ye : 0.0; ss += in ? se * se : 0.0; gg += in ? gpe * gpe : 0.0;
+              dv[t] = -gv[t];
+            }
+            vec_store<EPL>(sE, n, lane, sv);
+            vec_store<EPL>(yE, n, lane, yv);
+            vec_store<EPL>(S.d, n, lane, dv);
           }
           ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gg = wave_sum(gg);
           // 1/ys is stored instead of ys: one division per iteration instead of two per history pair.
@@ -206,10 +273,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             constexpr int PF = TOPAY_PF_ELEMS / EPL;  // pairs in flight
             SUBSTAMP_BEGIN(C);
             double dr[EPL];
+            {
+              double gv[EPL];
+              vec_load<EPL>(S.g, n, lane, gv);
 #pragma unroll
-            for (int t = 0; t < EPL; t++) {
-              const int e = lane + 64 * t;
-              dr[t] = e < n ? -S.g[e] : 0.0;
+              for (int t = 0; t < EPL; t++) dr[t] = (lane + 64 * t < n) ? -gv[t] : 0.0;
             }
             double sb[PF][EPL], yb[PF][EPL], rb[PF];
             double alr[4] = {0.0, 0.0, 0.0, 0.0};  // mem_size <= 256 (checked by topay_create)
@@ -299,7 +367,13 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
 
     if (go == GO_LS_BEGIN) {
       // lbfgs.hpp:559-573 + line-search prologue 288-311
-      for (int e = lane; e < n; e += 64) { S.xp[e] = S.x[e]; S.gp[e] = S.g[e]; }
+      {
+        double xv[EPL], gv[EPL];
+        vec_load<EPL>(S.x, n, lane, xv);
+        vec_load<EPL>(S.g, n, lane, gv);
+        vec_store<EPL>(S.xp, n, lane, xv);
+        vec_store<EPL>(S.gp, n, lane, gv);
+      }
       stp = step;
       count = 0;
       brackt = false;
@@ -309,7 +383,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       int err = 0;
       if (!(stp > 0.0)) err = TOPAY_LBFGSERR_INVALIDPARAMETERS;
       else {
-        dginit = vec_dot(S.gp, S.d, n, lane);
+        dginit = vec_dot<EPL>(S.gp, S.d, n, lane);
         if (0.0 < dginit) err = TOPAY_LBFGSERR_INCREASEGRADIENT;
       }
       if (err) {
@@ -319,7 +393,14 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         finit = fx;
         dgtest = lp.f_dec_coeff * dginit;
         dstest = lp.s_curv_coeff * dginit;
-        for (int e = lane; e < n; e += 64) S.x[e] = S.xp[e] + stp * S.d[e];
+        {
+          double pv[EPL], dv[EPL], xv[EPL];
+          vec_load<EPL>(S.xp, n, lane, pv);
+          vec_load<EPL>(S.d, n, lane, dv);
+#pragma unroll
+          for (int t = 0; t < EPL; t++) xv[t] = pv[t] + stp * dv[t];
+          vec_store<EPL>(S.x, n, lane, xv);
+        }
         mode = MODE_LS;
         go = GO_EVAL;
       }
