@@ -102,7 +102,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
   EvalCtx C;
   load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8]
+  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8] past costs, then [256] two-loop alpha
   SolveIO S;
   S.x = (glb_dp)(Bt.x + (size_t)b * Bt.nmax);
   S.g = (glb_dp)(Bt.work + ((size_t)b * 4 + 0) * Bt.nmax);
@@ -495,7 +495,8 @@ static int bucket_of(int N) {
     if (N <= kBucketMaxN[k]) return k;
   return topay_ctx::NBUCKET - 1;
 }
-static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8) * sizeof(double); }
+// + past-cost ring [8] + two-loop alpha ring [256]
+static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256) * sizeof(double); }
 
 static topay_status push_params(topay_ctx* c) {
   // contexts of one process may carry different parameters: refresh the constant block before every launch

@@ -66,7 +66,7 @@ __device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane)
 
 template <int RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8] */, int& success_out, double& cost_out) {
+                                                 lds_dp pf /* LDS [8 + 256] */, int& success_out, double& cost_out) {
   const DevParams& P = g_P;
   const int lane = C.lane, n = C.n;
   constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
@@ -264,12 +264,12 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             end = (end + 1) % mem;
             if (stage == 2) st_sumb += bound;
             // two-loop recursion (lbfgs.hpp:691-710) with the direction held in registers (element e = lane + 64 t).
-            // History pairs stream from HBM through a PF-deep register ring so that PF loads are always in flight
+            // History pairs stream from HBM through a PF-deep ring of register slots so that PF loads are always in flight
             // while the dependent dot-product / axpy chain runs.
             // Only loads may be in flight inside the loops (one store would make the memory counter unordered and
             // every wait a full drain), and every load is issued unconditionally so that the number outstanding is
-            // static: the alpha values live in a register ring (pair p -> lane p % 64, slot p / 64) and the prefetch
-            // keeps running past the end (it re-reads valid, unused rows).
+            // static: the alpha values live in LDS (256 doubles) and the prefetch keeps running past the end (it re-reads
+            // valid, unused rows).
             constexpr int PF = TOPAY_PF_ELEMS / EPL;  // pairs in flight
             SUBSTAMP_BEGIN(C);
             double dr[EPL];
@@ -280,10 +280,14 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
               for (int t = 0; t < EPL; t++) dr[t] = (lane + 64 * t < n) ? -gv[t] : 0.0;
             }
             double sb[PF][EPL], yb[PF][EPL], rb[PF];
-            double alr[4] = {0.0, 0.0, 0.0, 0.0};  // mem_size <= 256 (checked by topay_create)
+            lds_dp alpha = pf + 8;  // [mem <= 256]: every lane writes / reads the same entry (LDS broadcast)
+            // wave-uniform loop state in scalar registers (the values are uniform by construction; the compiler only
+            // sees that they were derived from vector compares)
+            const int endu = __builtin_amdgcn_readfirstlane(end), boundu = __builtin_amdgcn_readfirstlane(bound);
+            const int memu = __builtin_amdgcn_readfirstlane(mem), nstr = __builtin_amdgcn_readfirstlane(S.nstride);
             auto load_pair = [&](int slot, int jj) {
-              glb_cdp sj = S.hist_s + (size_t)jj * S.nstride;
-              glb_cdp yj = S.hist_y + (size_t)jj * S.nstride;
+              glb_cdp sj = S.hist_s + (size_t)jj * nstr;
+              glb_cdp yj = S.hist_y + (size_t)jj * nstr;
 #pragma unroll
               for (int t = 0; t < EPL; t++) {
                 const int e = lane + 64 * t;
@@ -295,61 +299,57 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
               rb[slot] = S.hist_ys[jj];
             };
             // ---- first loop: newest pair first.  Pair index of step i: (end - 1 - i) mod mem
-            int jl = end;  // next pair to load (walks down, wrapping)
+            int jl = endu;  // next pair to load (walks down, wrapping)
 #pragma unroll
-            for (int u = 0; u < PF; u++) { jl = jl == 0 ? mem - 1 : jl - 1; load_pair(u, jl); }
-            int jlast = end, jc = end;  // jc: pair being processed
-            for (int i0 = 0; i0 < bound; i0 += PF) {
+            for (int u = 0; u < PF; u++) { jl = jl == 0 ? memu - 1 : jl - 1; load_pair(u, jl); }
+            int jlast = endu, jc = endu;  // jc: pair being processed
+            for (int i0 = 0; i0 < boundu; i0 += PF) {
 #pragma unroll
               for (int u = 0; u < PF; u++) {
                 const int i = i0 + u;
-                if (i < bound) {
-                  jc = jc == 0 ? mem - 1 : jc - 1;
+                if (i < boundu) {
+                  jc = jc == 0 ? memu - 1 : jc - 1;
                   const int j = jc;
                   double part = 0.0;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
                   const double al = wave_sum(part) * rb[u];
-                  {
-                    const int sl = j >> 6, ln = j & 63;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) alr[k] = (sl == k && lane == ln) ? al : alr[k];
-                  }
+                  alpha[j] = al;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
                   jlast = j;
                 }
-                jl = jl == 0 ? mem - 1 : jl - 1;
+                jl = jl == 0 ? memu - 1 : jl - 1;
                 load_pair(u, jl);
               }
             }
             const double scl = ys / yy;
 #pragma unroll
             for (int t = 0; t < EPL; t++) dr[t] *= scl;
+            lds_sync();  // alpha entries written above are read below
             // ---- second loop: oldest pair first.  Pair index of step i: (jlast + i) mod mem
             jl = jlast;  // next pair to load (walks up, wrapping)
 #pragma unroll
-            for (int u = 0; u < PF; u++) { load_pair(u, jl); jl = jl + 1 == mem ? 0 : jl + 1; }
+            for (int u = 0; u < PF; u++) { load_pair(u, jl); jl = jl + 1 == memu ? 0 : jl + 1; }
             jc = jlast;
-            for (int i0 = 0; i0 < bound; i0 += PF) {
+            for (int i0 = 0; i0 < boundu; i0 += PF) {
 #pragma unroll
               for (int u = 0; u < PF; u++) {
                 const int i = i0 + u;
-                if (i < bound) {
+                if (i < boundu) {
                   const int j = jc;
-                  jc = jc + 1 == mem ? 0 : jc + 1;
+                  jc = jc + 1 == memu ? 0 : jc + 1;
+                  const double av = alpha[j];
                   double part = 0.0;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
                   const double beta = wave_sum(part) * rb[u];
-                  const int sl = j >> 6, ln = j & 63;
-                  const double av = sl == 0 ? alr[0] : (sl == 1 ? alr[1] : (sl == 2 ? alr[2] : alr[3]));
-                  const double co = readlane_f64(av, ln) - beta;
+                  const double co = av - beta;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
                 }
                 load_pair(u, jl);
-                jl = jl + 1 == mem ? 0 : jl + 1;
+                jl = jl + 1 == memu ? 0 : jl + 1;
               }
             }
 #pragma unroll
