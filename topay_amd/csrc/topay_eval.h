@@ -473,7 +473,7 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   const glb_cdp c_x = C.x;
 
   const DevParams& P = g_P;
-  const int lane = C.lane, N = C.N, rows = C.rows;
+  const int lane = C.lane, N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_dp band = c_X;
   lds_dp rdiag = c_X + 13 * rows;
   lds_dp cL = C.cL;
@@ -999,7 +999,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   const glb_cdp c_x = C.x;
 
   const DevParams& P = g_P;
-  const int lane = C.lane, N = C.N, rows = C.rows;
+  const int lane = C.lane, N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_cdp cL = C.cL;
   minco_generate(C);
 

@@ -47,7 +47,7 @@ __global__ void k_init(DevBatch Bt, const double* paths, const long long* path_o
 
 __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int init_stride_N) {
   C.lane = threadIdx.x;
-  C.N = Bt.N[b];
+  C.N = __builtin_amdgcn_readfirstlane(Bt.N[b]);  // wave-uniform: keep it (and what derives from it) in scalar registers
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
   carve(C, TOPAY_LDS_PTR, Nmax_lds);

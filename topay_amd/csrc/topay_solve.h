@@ -68,7 +68,7 @@ template <int RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
                                                  lds_dp pf /* LDS [8 + 256] */, int& success_out, double& cost_out) {
   const DevParams& P = g_P;
-  const int lane = C.lane, n = C.n;
+  const int lane = C.lane, n = __builtin_amdgcn_readfirstlane(C.n);
   constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
   int stage = 1;
   int alm_iter = 0;
