@@ -70,7 +70,7 @@ def main():
                     help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
                          "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
     ap.add_argument("--hires-size", type=float, default=50.0)
-    ap.add_argument("--inflight", type=int, default=2, help="batches (contexts) in flight per GPU; 1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=1, help="batches (contexts) in flight per GPU; 1 = strictly serial steps")
     args = ap.parse_args()
 
     import torch
