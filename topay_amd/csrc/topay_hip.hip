@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -434,7 +435,8 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     std::lock_guard<std::mutex> lk(g_bucket_mutex);
     for (int k = 0; k < topay_ctx::NBUCKET; k++)
       if (!g_bucket_streams[dev_slot][k])
-        HIPCHK(hipStreamCreateWithPriority(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking, kBucketPrio[k]));
+        HIPCHK(hipStreamCreateWithPriority(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking,
+                                           getenv("TOPAY_FLAT_PRIORITY") ? 0 : kBucketPrio[k]));
   }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     c->bstream[k] = g_bucket_streams[dev_slot][k];
