@@ -146,6 +146,19 @@ const char* topay_last_error(void);
 topay_status topay_set_map(topay_ctx* ctx, int map_id, const topay_map_desc_t* desc, const double* esdf2d,
                            const double* esdf3d);
 
+/* == GridMap::updateESDF (src/map/src/grid_map.cpp:125-521): build the 2-D and 3-D signed distance fields of map slot
+ * `map_id` ON THE DEVICE from the occupancy grids the reference fills from its point cloud (grid_map.cpp:733-747):
+ *   occ2d[x*dims[1] + y] (1 = a point below the chassis height), occ3d[x*dims[1]*dims[2] + y*dims[2] + z].
+ * Afterwards the slot is as if topay_set_map had been called with the CPU-built fields (bit-identical values).
+ * topay_get_map copies a resident map back and reports the duration of the last build in milliseconds. */
+topay_status topay_build_esdf(topay_ctx* ctx, int map_id, const topay_map_desc_t* desc, const signed char* occ2d,
+                              const signed char* occ3d);
+/* n_maps maps of equal dimensions in one set of launches (the benchmark loop regenerates the map every episode): the
+ * occupancy grids are concatenated map after map; slots first_map_id .. first_map_id + n_maps - 1 are filled. */
+topay_status topay_build_esdf_batch(topay_ctx* ctx, int n_maps, int first_map_id, const topay_map_desc_t* desc,
+                                    const signed char* occ2d, const signed char* occ3d);
+topay_status topay_get_map(topay_ctx* ctx, int map_id, double* esdf2d, double* esdf3d, double* build_ms);
+
 /* == optimizeTraj lines 146-357 for every batch member.
  *   path_len[b]      number of 10-d states of candidate b
  *   init_paths       ragged, sum(path_len) x 10, row-major (x, y, theta, q1..q7)

@@ -88,6 +88,10 @@ def load(path=None):
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
+    L.topay_build_esdf.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
+    L.topay_get_map.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
+    L.topay_build_esdf_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8),
+                                         C.POINTER(C.c_int8)]
     L.topay_get_total_durations.argtypes = [C.c_void_p, c_dp]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
     L.topay_feasibility_report.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
@@ -140,6 +144,7 @@ class MomaTrajOptBatch:
         self.h = h
         self.batch = 0
         self.traj_cost = None
+        self._map_dims = {}
 
     def close(self):
         if getattr(self, "h", None):
@@ -164,6 +169,7 @@ class MomaTrajOptBatch:
         e2 = np.ascontiguousarray(esdf2d, dtype=np.float64)
         e3 = np.ascontiguousarray(esdf3d, dtype=np.float64)
         _chk(self.L, self.L.topay_set_map(self.h, map_id, C.byref(d), _dp(e2), _dp(e3)))
+        self._map_dims[map_id] = tuple(int(x) for x in dims)
 
     # -- optimizeTraj lines 146-357
     def set_init_traj(self, path_len, init_paths, boundary_vel=None, boundary_acc=None, map_ids=None):
@@ -245,6 +251,41 @@ class MomaTrajOptBatch:
         t = np.zeros(self.batch)
         _chk(self.L, self.L.topay_get_total_durations(self.h, _dp(t)))
         return t
+
+    def build_esdf(self, origin, res, dims, min_b, max_b, occ2d, occ3d, map_id=0):
+        """GridMap::updateESDF on the device from the occupancy grids; the slot is then usable like after set_map."""
+        d = MapDesc()
+        for k in range(3):
+            d.origin[k] = origin[k]; d.dims[k] = int(dims[k]); d.min_boundary[k] = min_b[k]; d.max_boundary[k] = max_b[k]
+        d.resolution = res
+        o2 = np.ascontiguousarray(occ2d, dtype=np.int8)
+        o3 = np.ascontiguousarray(occ3d, dtype=np.int8)
+        _chk(self.L, self.L.topay_build_esdf(self.h, map_id, C.byref(d), o2.ctypes.data_as(C.POINTER(C.c_int8)),
+                                             o3.ctypes.data_as(C.POINTER(C.c_int8))))
+        self._map_dims[map_id] = tuple(int(x) for x in dims)
+
+    def build_esdf_batch(self, origin, res, dims, min_b, max_b, occ2d_all, occ3d_all, first_map_id=0):
+        """Same for a batch of equally sized maps: occ*_all are [n_maps, cells] arrays."""
+        d = MapDesc()
+        for k in range(3):
+            d.origin[k] = origin[k]; d.dims[k] = int(dims[k]); d.min_boundary[k] = min_b[k]; d.max_boundary[k] = max_b[k]
+        d.resolution = res
+        o2 = np.ascontiguousarray(occ2d_all, dtype=np.int8)
+        o3 = np.ascontiguousarray(occ3d_all, dtype=np.int8)
+        n_maps = o2.shape[0]
+        _chk(self.L, self.L.topay_build_esdf_batch(self.h, n_maps, first_map_id, C.byref(d), o2.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                   o3.ctypes.data_as(C.POINTER(C.c_int8))))
+        for k in range(n_maps):
+            self._map_dims[first_map_id + k] = tuple(int(x) for x in dims)
+
+    def get_map(self, map_id=0):
+        """(esdf2d, esdf3d, build_ms) of a resident map."""
+        nx, ny, nz = self._map_dims[map_id]
+        e2 = np.zeros(nx * ny)
+        e3 = np.zeros(nx * ny * nz)
+        ms = C.c_double(0)
+        _chk(self.L, self.L.topay_get_map(self.h, map_id, _dp(e2), _dp(e3), C.byref(ms)))
+        return e2, e3, ms.value
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

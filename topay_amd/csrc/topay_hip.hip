@@ -14,6 +14,7 @@
 
 #include "topay_solve.h"
 #include "topay_feas.h"
+#include "topay_edt.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
 // One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
@@ -272,7 +273,8 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3;
+  float last_edt_ms = 0.f;
   int trace_cap = 0;
   DevBatch db;
   bool have_traj = false, solved = false;
@@ -454,7 +456,8 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags};
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
+                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
@@ -515,6 +518,108 @@ static topay_status run_init(topay_ctx* c) {
                      c->path_off.as<long long>(), c->path_len.as<int>(), c->bvel.as<double>(), c->bacc.as<double>(),
                      c->scratch.as<double>(), scratch_stride, TOPAY_MAX_N, 10 * TOPAY_MAX_N - 8);
   HIPCHK(hipGetLastError());
+  return TOPAY_OK;
+}
+
+// ESDF construction on the device (GridMap::updateESDF, grid_map.cpp:125-521) from the occupancy grids the
+// reference fills from its point cloud (grid_map.cpp:733-747): occ2d[x*ny + y] (points below the chassis height),
+// occ3d[x*ny*nz + y*nz + z].  The map slots then hold the result exactly as topay_set_map would.  A batch of maps
+// of equal dimensions (the benchmark loop: one map per scenario) is built by the same launches, blockIdx.y = map:
+// a single 200 x 200 x 16 map has too few lines to fill the device.
+topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, const topay_map_desc_t* desc,
+                                    const signed char* occ2d, const signed char* occ3d) {
+  if (!c || !desc || !occ2d || !occ3d || n_maps <= 0 || first_map_id < 0 || first_map_id + n_maps > TOPAY_MAX_MAPS)
+    return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const int nx = desc->dims[0], ny = desc->dims[1], nz = desc->dims[2];
+  const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, M = (size_t)n_maps;
+  if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
+  topay_status s;
+  if ((s = c->edt_occ.ensure(M * (n3 + n2))) != TOPAY_OK) return s;
+  if ((s = c->edt_tmp1.ensure(M * n3 * 8)) != TOPAY_OK) return s;
+  if ((s = c->edt_tmp2.ensure(M * n3 * 8)) != TOPAY_OK) return s;
+  if ((s = c->edt_out3.ensure(M * n3 * 8)) != TOPAY_OK) return s;
+  if ((s = c->edt_out2.ensure(M * n2 * 8)) != TOPAY_OK) return s;
+  // workspace for the envelope stacks of the pass with the most (lines x cells), per map
+  const size_t ws_elems = std::max(std::max((size_t)nx * ny * (nz + 2), (size_t)nx * nz * (ny + 2)), (size_t)ny * nz * (nx + 2));
+  if ((s = c->edt_v.ensure(M * ws_elems * 4)) != TOPAY_OK) return s;
+  if ((s = c->edt_z.ensure(M * ws_elems * 8)) != TOPAY_OK) return s;
+  signed char* d_occ3 = c->edt_occ.as<signed char>();
+  signed char* d_occ2 = d_occ3 + M * n3;
+  HIPCHK(hipMemcpyAsync(d_occ3, occ3d, M * n3, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_occ2, occ2d, M * n2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  double* t1 = c->edt_tmp1.as<double>();
+  double* t2 = c->edt_tmp2.as<double>();
+  double* e3 = c->edt_out3.as<double>();
+  double* e2 = c->edt_out2.as<double>();
+  int* vws = c->edt_v.as<int>();
+  double* zws = c->edt_z.as<double>();
+  const double res = desc->resolution;
+  auto launch = [&](auto kern, EdtPass P, long long map_stride, const signed char* occ, const double* src, double* dst, int pass) {
+    const int bs = 64;
+    P.map_stride = map_stride;
+    P.ws_stride = (long long)ws_elems;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((P.nlines + bs - 1) / bs), (unsigned)n_maps), dim3(bs), 0, c->stream, P, occ, src, dst,
+                       vws, zws, pass, res);
+  };
+  for (int pass = 0; pass < 2; pass++) {
+    // 3-D: along z (lines (x, y)), along y (lines (x, z)), along x (lines (y, z)) — grid_map.cpp:425-521
+    EdtPass pz{(long long)nx * ny, nz, (long long)nx * ny, 0, (long long)nz, 1, 0, 0};
+    EdtPass py{(long long)nx * nz, ny, (long long)nz, (long long)ny * nz, 1, (long long)nz, 0, 0};
+    EdtPass px{(long long)ny * nz, nx, (long long)ny * nz, 0, 1, (long long)ny * nz, 0, 0};
+    launch(k_edt_pass<0, 0>, pz, (long long)n3, d_occ3, nullptr, t1, pass);
+    launch(k_edt_pass<1, 0>, py, (long long)n3, nullptr, t1, t2, pass);
+    launch(k_edt_pass<1, 1>, px, (long long)n3, nullptr, t2, e3, pass);
+    // 2-D: along y (lines x), along x (lines y) — grid_map.cpp:125-207
+    EdtPass qy{(long long)nx, ny, (long long)nx, 0, (long long)ny, 1, 0, 0};
+    EdtPass qx{(long long)ny, nx, (long long)ny, 0, 1, (long long)ny, 0, 0};
+    launch(k_edt_pass<0, 0>, qy, (long long)n2, d_occ2, nullptr, t1, pass);
+    launch(k_edt_pass<1, 1>, qx, (long long)n2, nullptr, t1, e2, pass);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  // into the map slots (device to device), descriptors as topay_set_map
+  for (int k = 0; k < n_maps; k++) {
+    const int map_id = first_map_id + k;
+    if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
+    if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
+    HIPCHK(hipMemcpyAsync(c->map2d[map_id].p, e2 + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->map3d[map_id].p, e3 + (size_t)k * n3, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+    DevMap& m = c->hmaps[map_id];
+    for (int i = 0; i < 3; i++) {
+      m.origin[i] = desc->origin[i]; m.dims[i] = desc->dims[i];
+      m.min_b[i] = desc->min_boundary[i]; m.max_b[i] = desc->max_boundary[i];
+    }
+    m.res = desc->resolution;
+    m.res_inv = 1.0 / desc->resolution;
+    m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
+    m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
+    c->have_map[map_id] = 1;
+  }
+  HIPCHK(hipMemcpyAsync((char*)c->dmaps.p + sizeof(DevMap) * first_map_id, &c->hmaps[first_map_id], sizeof(DevMap) * n_maps,
+                        hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_edt_ms = ms;
+  return TOPAY_OK;
+}
+
+topay_status topay_build_esdf(topay_ctx* c, int map_id, const topay_map_desc_t* desc, const signed char* occ2d,
+                              const signed char* occ3d) {
+  return topay_build_esdf_batch(c, 1, map_id, desc, occ2d, occ3d);
+}
+
+// Copy a resident map back (tests, or a caller that wants the GPU-built ESDF on the host); milliseconds of the last build.
+topay_status topay_get_map(topay_ctx* c, int map_id, double* esdf2d, double* esdf3d, double* build_ms) {
+  if (!c || map_id < 0 || map_id >= TOPAY_MAX_MAPS || !c->have_map[map_id]) return TOPAY_ERR_NO_MAP;
+  HIPCHK(hipSetDevice(c->device));
+  const DevMap& m = c->hmaps[map_id];
+  const size_t n2 = (size_t)m.dims[0] * m.dims[1], n3 = n2 * m.dims[2];
+  if (esdf2d) HIPCHK(hipMemcpy(esdf2d, c->map2d[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf3d) HIPCHK(hipMemcpy(esdf3d, c->map3d[map_id].p, n3 * 8, hipMemcpyDeviceToHost));
+  if (build_ms) *build_ms = c->last_edt_ms;
   return TOPAY_OK;
 }
 

@@ -35,6 +35,10 @@ def lib():
         L.wl_world_esdf2d.restype = c_dp
         L.wl_world_esdf3d.restype = c_dp
         L.wl_world_esdf2d.argtypes = [C.c_void_p]
+        L.wl_world_occ2d.restype = C.POINTER(C.c_int8)
+        L.wl_world_occ3d.restype = C.POINTER(C.c_int8)
+        L.wl_world_occ2d.argtypes = [C.c_void_p]
+        L.wl_world_occ3d.argtypes = [C.c_void_p]
         L.wl_world_esdf3d.argtypes = [C.c_void_p]
         L.wl_world_destroy.argtypes = [C.c_void_p]
         L.wl_world_desc.argtypes = [C.c_void_p, c_ip, c_dp, c_dp, c_dp, c_dp]
@@ -85,6 +89,8 @@ class World:
         n3 = n2 * int(dims[2])
         self.esdf2d = np.ctypeslib.as_array(L.wl_world_esdf2d(self.h), shape=(n2,))
         self.esdf3d = np.ctypeslib.as_array(L.wl_world_esdf3d(self.h), shape=(n3,))
+        self.occ2d = np.ctypeslib.as_array(L.wl_world_occ2d(self.h), shape=(n2,))
+        self.occ3d = np.ctypeslib.as_array(L.wl_world_occ3d(self.h), shape=(n3,))
 
     def close(self):
         if self.h:
