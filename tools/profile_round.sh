@@ -10,6 +10,7 @@ ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1"   # strictly
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/bench_kt.json 2> $OUT/kt.log
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log
+[ -x $ROOT/tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/tools/pmc_calib $ROOT/tools/pmc_calib.hip 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- $ROOT/tools/pmc_calib > $OUT/calib.txt 2> $OUT/cal_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- $ROOT/tools/pmc_calib >> $OUT/calib.txt 2> $OUT/cal_write.log
 python3 $ROOT/bench.py $ARGS > $OUT/bench_plain.json 2>/dev/null
