@@ -204,6 +204,13 @@ topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
  * device clock (only differences are meaningful).  Either pointer may be NULL. */
 topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
 
+/* MomaTraj playback of candidate i (moma_traj_opt.h:26-137): car_seq -- (x, y, theta, t) every 0.1 s from Simpson
+ * panels of 0.025 s, what the reference stores in the trajectory object and publishes -- and getState(t) at caller-given
+ * times, states[n_times][10] = (x, y, theta, q1..q7).  seq (seq_cap rows of 4 doubles) may be NULL; *n_seq receives the
+ * number of car_seq entries. */
+topay_status topay_playback(topay_ctx* ctx, int i, int n_times, const double* times, double* states, int seq_cap,
+                            double* seq, int* n_seq);
+
 /* Total duration of every candidate's returned trajectory (MomaTraj::getTotalDuration): the quantity the planner ranks
  * the successful candidates of a scenario by (planner.cpp:999-1010). */
 topay_status topay_get_total_durations(topay_ctx* ctx, double* total /* batch */);

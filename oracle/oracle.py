@@ -182,6 +182,11 @@ class Oracle:
         f = self.L.orc_check_feasible(self.h, _dp(rep), C.byref(st))
         return bool(f), bool(st.value), rep
 
+    def car_seq(self):
+        seq = np.zeros((4096, 4))
+        n = self.L.orc_car_seq(self.h, _dp(seq), 4096)
+        return seq[:n].copy()
+
     def traj_state(self, t):
         s = np.zeros(10)
         self.L.orc_traj_state(self.h, C.c_double(t), _dp(s))

@@ -147,6 +147,13 @@ int orc_check_feasible(void* hh, double* report38, int* strict) {
   if (strict) *strict = st ? 1 : 0;
   return f ? 1 : 0;
 }
+// car_seq of the trajectory currently held: returns the number of entries, fills up to cap rows of (x, y, theta, t)
+int orc_car_seq(void* hh, double* seq, int cap) {
+  const auto s = ((OracleHandle*)hh)->opt.carSeq();
+  for (size_t k = 0; k < s.size() && (int)k < cap; k++)
+    for (int q = 0; q < 4; q++) seq[4 * k + q] = s[k][q];
+  return (int)s.size();
+}
 // MomaTraj::getState(t) of the trajectory currently held (10 values)
 void orc_traj_state(void* hh, double t, double* state10) {
   auto& o = ((OracleHandle*)hh)->opt;

@@ -97,3 +97,36 @@ def test_gate_on_gpu_matches_emulator_and_oracle():
         _, (fo, so, ro) = _oracle_gate(m, paths[offs[b]:offs[b + 1]], gpu.get_x(b), alm[b])
         assert fo == fg[b] and so == sg[b]
         assert np.allclose(np.abs(ro), rg[b], rtol=1e-9, atol=1e-11)
+
+
+def test_playback_matches_oracle(cuboids_small):
+    """car_seq and getState of the kernel sources (CPU lane emulator) against the oracle's MomaTraj restatement."""
+    cs = cuboids_small
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    lens, paths = cs["lens"][:2], cs["paths"][:cs["offs"][2]]
+    emu.optimizeTraj(lens, paths)
+    alm = emu.alm_state()
+    for b in range(2):
+        o, _ = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
+        T = emu.total_durations()[b]
+        times = np.concatenate([[0.0, T, T + 1.0, -0.5], np.linspace(0, T, 37)])
+        st, seq = emu.playback(b, times)
+        seq_o = o.car_seq()
+        assert len(seq) == len(seq_o) and np.allclose(seq, seq_o, rtol=0, atol=1e-11)
+        for k, t in enumerate(times):
+            assert np.allclose(st[k], o.traj_state(float(t)), rtol=0, atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_playback_on_gpu_is_bit_identical_to_emulator(cuboids_small):
+    cs = cuboids_small
+    lens, paths = cs["lens"][:1], cs["paths"][:cs["offs"][1]]
+    out = {}
+    for name, lib in (("gpu", None), ("emu", EMU_LIB)):
+        opt = api.MomaTrajOptBatch(device=0, lib_path=lib)
+        set_map(opt, cs["world"])
+        opt.optimizeTraj(lens, paths)
+        T = opt.total_durations()[0]
+        out[name] = opt.playback(0, np.linspace(-0.2, T + 0.2, 211))
+    assert (out["gpu"][0] == out["emu"][0]).all() and (out["gpu"][1] == out["emu"][1]).all()

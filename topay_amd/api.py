@@ -88,6 +88,7 @@ def load(path=None):
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
+    L.topay_playback.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, C.c_int, c_dp, c_ip]
     L.topay_build_esdf.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.topay_get_map.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
     L.topay_build_esdf_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8),
@@ -286,6 +287,16 @@ class MomaTrajOptBatch:
         ms = C.c_double(0)
         _chk(self.L, self.L.topay_get_map(self.h, map_id, _dp(e2), _dp(e3), C.byref(ms)))
         return e2, e3, ms.value
+
+    def playback(self, i, times):
+        """MomaTraj playback of candidate i: (states[len(times), 10], car_seq[n, 4])."""
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        st = np.zeros((len(t), 10))
+        cap = 4096
+        seq = np.zeros((cap, 4))
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_playback(self.h, i, len(t), _dp(t), _dp(st), cap, _dp(seq), C.byref(n)))
+        return st, seq[:min(n.value, cap)].copy()
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

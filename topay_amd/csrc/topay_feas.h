@@ -250,4 +250,82 @@ __device__ __forceinline__ void feasibility_gate(const FeasIO& F, const TOPAY_GL
   }
 }
 
+// MomaTraj playback of one candidate — car_seq (moma_traj_opt.h:40-69) and getState (113-137) at caller-given times.
+// One wavefront: car_seq panels by a wave scan exactly as in the gate, then lanes <-> query times.
+//   seq_out  [(nseq)][4] = (x, y, theta, t) every 0.1 s, nseq = floor(floor(T / 0.025) / 4) + 1
+//   states   [nq][10]    = getState(times[q])
+__device__ __forceinline__ void playback(const FeasIO& F, int nq, const double* times, double* states, double* seq_out,
+                                         int* nseq_out) {
+  const int lane = threadIdx.x & 63;
+  const int N = F.N, rows = 6 * N;
+  double Ttot = 0.0;
+  for (int i = 0; i < N; i++) Ttot += F.T[i];
+  if (!(Ttot > 0.0 && Ttot < 1.0e4)) {
+    if (lane == 0 && nseq_out) *nseq_out = 0;
+    return;
+  }
+  const double seq_res = 0.1;
+  const int approx_res = 4;
+  const double h = seq_res / approx_res, hh = h / 2.0, h6 = h / 6.0;
+  long long num = (long long)floor(Ttot / h);
+  if (num > F.cap_panels) num = F.cap_panels;
+  if (lane == 0) { F.cseq[0] = F.x0; F.cseq[1] = F.y0; }
+  double carryx = 0.0, carryy = 0.0;
+  for (long long p0 = 0; p0 < num; p0 += 64) {
+    const long long i = p0 + lane;
+    double ix = 0.0, iy = 0.0;
+    if (i < num) {
+      const double ta = i == 0 ? 0.0 : (double)(i - 1) * h + h;
+      feas_simpson(F, ta, (double)i * h + hh, (double)i * h + h, h6, ix, iy);
+    }
+    const double sx = wave_incl_scan(ix, lane), sy = wave_incl_scan(iy, lane);
+    if (i < num) {
+      F.cseq[2 * (i + 1)] = F.x0 + (carryx + sx);
+      F.cseq[2 * (i + 1) + 1] = F.y0 + (carryy + sy);
+    }
+    carryx += __shfl(sx, 63);
+    carryy += __shfl(sy, 63);
+  }
+  __syncthreads();
+  const long long nseq = num / approx_res + 1;
+  if (seq_out) {
+    for (long long k = lane; k < nseq; k += 64) {
+      double th = F.th0, tt = 0.0;
+      if (k > 0) {
+        const long long i = k * approx_res - 1;        // the panel after which the entry is pushed
+        tt = (double)(i + 1) * h;
+        double tl = (double)i * h + h;                  // p3 of that panel
+        const int pi = feas_locate(F.T, N, tl);
+        th = feas_pos(F.coef + 0 * rows + 6 * pi, tl);
+      }
+      seq_out[4 * k] = F.cseq[2 * k * approx_res];
+      seq_out[4 * k + 1] = F.cseq[2 * k * approx_res + 1];
+      seq_out[4 * k + 2] = th;
+      seq_out[4 * k + 3] = tt;
+    }
+  }
+  if (lane == 0 && nseq_out) *nseq_out = (int)nseq;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int q = q0 + lane;
+    if (q < nq) {
+      double tg = times[q];
+      tg = fmin(fmax(tg, 0.0), Ttot);
+      const int index = (int)floor(tg / seq_res);
+      const double floor_t = index * seq_res, diff_t = tg - floor_t;
+      long long pidx = (long long)index * approx_res;
+      if (pidx > num) pidx = num;
+      double ix, iy;
+      feas_simpson(F, floor_t, floor_t + diff_t / 2.0, tg, diff_t / 6.0, ix, iy);
+      double tl = tg;
+      const int i = feas_locate(F.T, N, tl);
+      double* o = states + (size_t)q * 10;
+      o[0] = F.cseq[2 * pidx] + ix;
+      o[1] = F.cseq[2 * pidx + 1] + iy;
+      o[2] = feas_pos(F.coef + 0 * rows + 6 * i, tl);
+#pragma unroll
+      for (int d = 0; d < 7; d++) o[3 + d] = feas_pos(F.coef + (2 + d) * rows + 6 * i, tl);
+    }
+  }
+}
+
 }  // namespace topay

@@ -191,6 +191,28 @@ __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps
   feasibility_gate(F, mp);
 }
 
+// MomaTraj playback of one candidate (car_seq + getState at given times)
+__global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cseq, long long cap_panels, int nq, const double* times,
+                                                 double* states, double* seq_out, int* nseq_out) {
+  const int N = Bt.N[b];
+  if (N <= 0) {
+    if (threadIdx.x == 0) *nseq_out = 0;
+    return;
+  }
+  FeasIO F;
+  F.coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
+  F.T = Bt.T + (size_t)b * Bt.Nmax;
+  F.N = N;
+  F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
+  F.th0 = Bt.head[(size_t)b * 27];
+  F.cseq = cseq;
+  F.tk = nullptr;
+  F.cap_panels = cap_panels; F.cap_samples = 0;
+  F.report = nullptr;
+  F.feasible = nullptr;
+  playback(F, nq, times, states, seq_out, nseq_out);
+}
+
 // test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
 __global__ void k_math(const double* a, const double* b, double* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,7 +295,7 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
   float last_edt_ms = 0.f;
   int trace_cap = 0;
   DevBatch db;
@@ -457,7 +479,7 @@ void topay_destroy(topay_ctx* c) {
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
-                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3};
+                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
@@ -849,6 +871,42 @@ topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us) {
   HIPCHK(hipSetDevice(c->device));
   if (us) HIPCHK(hipMemcpy(us, c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   if (start_us) HIPCHK(hipMemcpy(start_us, c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+// MomaTraj playback of candidate i: car_seq (x, y, theta, t every 0.1 s; moma_traj_opt.h:40-69) and getState at the
+// given times (113-137).  seq may be NULL; *n_seq receives the number of entries (capacity seq_cap rows of 4).
+topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* times, double* states, int seq_cap, double* seq,
+                            int* n_seq) {
+  if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B || n_times < 0 || (n_times > 0 && (!times || !states))) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<double> hT((size_t)c->Nmax);
+  HIPCHK(hipMemcpy(hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
+  double t = 0.0;
+  for (int k = 0; k < c->hN[i]; k++) t += hT[k];
+  if (!(t > 0.0 && t < 1.0e4)) t = 0.0;
+  const long long cap_panels = (long long)(t / 0.025) + 4;
+  const long long nseq_max = cap_panels / 4 + 2;
+  topay_status s;
+  if ((s = c->feas_cseq.ensure((size_t)2 * (cap_panels + 1) * 8)) != TOPAY_OK) return s;
+  if ((s = c->pb_io.ensure((size_t)(n_times * 11 + nseq_max * 4 + 2) * 8)) != TOPAY_OK) return s;
+  double* d_times = c->pb_io.as<double>();
+  double* d_states = d_times + n_times;
+  double* d_seq = d_states + (size_t)n_times * 10;
+  int* d_nseq = (int*)(d_seq + nseq_max * 4);
+  if (n_times) HIPCHK(hipMemcpyAsync(d_times, times, (size_t)n_times * 8, hipMemcpyHostToDevice, c->stream));
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  hipLaunchKernelGGL(k_playback, dim3(1), dim3(64), 0, c->stream, c->db, i, c->feas_cseq.as<double>(), cap_panels, n_times,
+                     (const double*)d_times, d_states, d_seq, d_nseq);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int ns = 0;
+  HIPCHK(hipMemcpy(&ns, d_nseq, 4, hipMemcpyDeviceToHost));
+  if (n_seq) *n_seq = ns;
+  if (seq && ns > 0) HIPCHK(hipMemcpy(seq, d_seq, (size_t)std::min(ns, seq_cap) * 4 * 8, hipMemcpyDeviceToHost));
+  if (n_times) HIPCHK(hipMemcpy(states, d_states, (size_t)n_times * 10 * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
