@@ -204,6 +204,12 @@ topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
  * device clock (only differences are meaningful).  Either pointer may be NULL. */
 topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
 
+/* == GridMap::isWholeBodyCollision (src/map/include/map/grid_map.h:613-650) for n states (x, y, theta, q1..q7) against
+ * map slot map_id: collide[i] = 1 when state i violates a joint limit, lies outside the map or collides (chassis, the 12
+ * arm spheres against the environment, the chassis top and each other).  The check the front-end applies to every state
+ * it samples or interpolates (mcrrts.cpp, planner.cpp:529-548). */
+topay_status topay_whole_body_collision(topay_ctx* ctx, int map_id, int n, const double* states, int* collide);
+
 /* MomaTraj playback of candidate i (moma_traj_opt.h:26-137): car_seq -- (x, y, theta, t) every 0.1 s from Simpson
  * panels of 0.025 s, what the reference stores in the trajectory object and publishes -- and getState(t) at caller-given
  * times, states[n_times][10] = (x, y, theta, q1..q7).  seq (seq_cap rows of 4 doubles) may be NULL; *n_seq receives the

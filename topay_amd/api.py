@@ -88,6 +88,7 @@ def load(path=None):
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
+    L.topay_whole_body_collision.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_ip]
     L.topay_playback.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, C.c_int, c_dp, c_ip]
     L.topay_build_esdf.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.topay_get_map.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
@@ -297,6 +298,13 @@ class MomaTrajOptBatch:
         n = C.c_int(0)
         _chk(self.L, self.L.topay_playback(self.h, i, len(t), _dp(t), _dp(st), cap, _dp(seq), C.byref(n)))
         return st, seq[:min(n.value, cap)].copy()
+
+    def whole_body_collision(self, states, map_id=0):
+        """GridMap::isWholeBodyCollision for an [n, 10] array of states -> bool array."""
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 10)
+        out = np.zeros(len(st), dtype=np.int32)
+        _chk(self.L, self.L.topay_whole_body_collision(self.h, map_id, len(st), _dp(st), _ip(out)))
+        return out.astype(bool)
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

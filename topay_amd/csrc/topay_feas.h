@@ -328,4 +328,72 @@ __device__ __forceinline__ void playback(const FeasIO& F, int nq, const double* 
   }
 }
 
+// GridMap::isWholeBodyCollision (src/map/include/map/grid_map.h:613-650): the check the front-end applies to every
+// sampled or interpolated state (joint limits, chassis against the 2-D field, every sphere against the 3-D field,
+// spheres against the chassis top and against each other).  A point outside the map counts as a collision
+// (isCollision2d / isCollision3d, grid_map.h:511-536, 699-725).  One thread per state.
+__device__ __forceinline__ bool whole_body_collision(const DevMap& M, const double* st) {
+  const DevParams& P = g_P;
+  bool hit = false;
+#pragma unroll
+  for (int q = 0; q < 7; q++) hit = hit || st[3 + q] > P.joint_pos_limit_max[q] || st[3 + q] < -P.joint_pos_limit_max[q];
+  {
+    const double d = feas_dist2d(M, st[0], st[1]);   // 1e10 outside the map
+    const bool in = d < 1.0e+9;
+    hit = hit || !in || d < P.chassis_colli_radius;
+  }
+  double sq[7], cq[7], sth, cth;
+#pragma unroll
+  for (int q = 0; q < 7; q++) det_sincos(st[3 + q], &sq[q], &cq[q]);
+  det_sincos(st[2], &sth, &cth);
+  double A[9];
+  {
+    const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++)
+        A[a * 3 + b] = Rz[a * 3 + 0] * P.relR[0 * 3 + b] + Rz[a * 3 + 1] * P.relR[1 * 3 + b] + Rz[a * 3 + 2] * P.relR[2 * 3 + b];
+  }
+  const double p0x = st[0] + (cth * P.relT[0] - sth * P.relT[1]);
+  const double p0y = st[1] + (sth * P.relT[0] + cth * P.relT[1]);
+  const double p0z = P.chassis_height + P.relT[2];
+  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
+  double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+  int sidx = 0;
+#pragma unroll
+  for (int li = 0; li < 8; li++) {
+    const int cnt = (li % 2 == 0) ? 2 : 1;
+#pragma unroll
+    for (int c = 0; c < cnt; c++) {
+      const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
+      Px[sidx] = p0x + fma(A[2], lz, fma(A[1], ly, A[0] * lx));
+      Py[sidx] = p0y + fma(A[5], lz, fma(A[4], ly, A[3] * lx));
+      Pz[sidx] = p0z + fma(A[8], lz, fma(A[7], ly, A[6] * lx));
+      sidx++;
+    }
+    q0 = fma(R[2], P.colli_length[li], q0);
+    q1 = fma(R[5], P.colli_length[li], q1);
+    q2 = fma(R[8], P.colli_length[li], q2);
+    if (li == 7) break;
+    joint_rotate(R, li, cq[li], sq[li]);
+  }
+#pragma unroll
+  for (int i = 0; i < TOPAY_NSPH; i++) {
+    const double d = feas_dist3d(M, Px[i], Py[i], Pz[i]);
+    hit = hit || !(d < 1.0e+9) || d < P.sph_r[i];
+    if (i > 2) {
+      const double dx = Px[i] - st[0], dy = Py[i] - st[1];
+      hit = hit || (Pz[i] < P.chassis_height + P.sph_r[i] && sqrt(dx * dx + dy * dy) < P.chassis_colli_radius + P.sph_r[i]);
+    }
+#pragma unroll
+    for (int j = i + 2; j < TOPAY_NSPH; j++) {  // collision_matrix == -1: non-adjacent spheres (moma_param.h:128-143)
+      const double d0 = Px[i] - Px[j], d1 = Py[i] - Py[j], d2 = Pz[i] - Pz[j];
+      hit = hit || sqrt(d0 * d0 + d1 * d1 + d2 * d2) < P.sph_r[i] + P.sph_r[j];
+    }
+  }
+  return hit;
+}
+
 }  // namespace topay

@@ -213,6 +213,14 @@ __global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cse
   playback(F, nq, times, states, seq_out, nseq_out);
 }
 
+// GridMap::isWholeBodyCollision for a batch of states
+__global__ void k_whole_body(const DevMap* maps, int map_id, int n, const double* states, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const DevMap M = maps[map_id];
+  out[i] = whole_body_collision(M, states + (size_t)i * 10) ? 1 : 0;
+}
+
 // test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
 __global__ void k_math(const double* a, const double* b, double* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,6 +915,28 @@ topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* time
   if (n_seq) *n_seq = ns;
   if (seq && ns > 0) HIPCHK(hipMemcpy(seq, d_seq, (size_t)std::min(ns, seq_cap) * 4 * 8, hipMemcpyDeviceToHost));
   if (n_times) HIPCHK(hipMemcpy(states, d_states, (size_t)n_times * 10 * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+// GridMap::isWholeBodyCollision (grid_map.h:613-650) of n states (x, y, theta, q1..q7) against map slot map_id:
+// collide[i] = 1 when the state violates a joint limit, leaves the map or collides (front-end building block).
+topay_status topay_whole_body_collision(topay_ctx* c, int map_id, int n, const double* states, int* collide) {
+  if (!c || !states || !collide || n < 0 || map_id < 0 || map_id >= TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
+  if (!c->have_map[map_id]) return TOPAY_ERR_NO_MAP;
+  if (n == 0) return TOPAY_OK;
+  HIPCHK(hipSetDevice(c->device));
+  topay_status s;
+  if ((s = c->pb_io.ensure((size_t)n * 10 * 8 + (size_t)n * 4)) != TOPAY_OK) return s;
+  double* d_st = c->pb_io.as<double>();
+  int* d_out = (int*)(d_st + (size_t)n * 10);
+  HIPCHK(hipMemcpyAsync(d_st, states, (size_t)n * 80, hipMemcpyHostToDevice, c->stream));
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  hipLaunchKernelGGL(k_whole_body, dim3((n + 63) / 64), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, map_id, n,
+                     (const double*)d_st, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(collide, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return TOPAY_OK;
 }
 
