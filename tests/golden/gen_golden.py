@@ -56,8 +56,10 @@ def main():
     ok = o3.optimize()
     st = o3.stats()
     d, c, k = o3.get_traj()
+    feas, strict, rep = o3.check_feasible()      # printConstraintsSituations / checkFeasible on that trajectory
     out.update(full_ok=int(ok), full_stats=np.array([st[key] for key in st]), full_cost=o3.traj_cost(), full_dur=d,
-               full_knots=k, full_coeffs=c)
+               full_knots=k, full_coeffs=c, full_x=o3.get_x(), full_gate=np.array([int(feas), int(strict)]), full_gate_report=rep,
+               full_car_seq=o3.car_seq(), full_state_mid=o3.traj_state(0.37 * d.sum()))
     np.savez_compressed(os.path.join(HERE, "cuboids_seed42.npz"), **out)
     print("wrote", os.path.join(HERE, "cuboids_seed42.npz"))
 
