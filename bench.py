@@ -185,6 +185,22 @@ def main():
     else:
         total_traj = float(B)
 
+    # BASELINE configs[1] (one tables scenario x 64 candidates) as a latency figure beside the throughput line: the batch
+    # is far too small to fill the device (64 wavefronts), so its time is the longest candidate's.
+    cfg1 = None
+    if rank == 0 and not hires:
+        w1, _, _, lens1, paths1 = wl.tables_scenario(0, 64)
+        o1 = api.MomaTrajOptBatch(device=local_rank)
+        o1.set_map(w1.origin, w1.res, w1.dims, w1.min_b, w1.max_b, w1.esdf2d, w1.esdf3d)
+        o1.set_init_traj(lens1, paths1)
+        o1.optimize()
+        o1.reset()
+        ok1 = o1.optimize()
+        ms1, _ = o1.last_kernel_ms()
+        cfg1 = {"workload": "BASELINE configs[1]: 1 tables scenario x 64 candidates", "solve_ms": float(ms1),
+                "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
+        o1.close()
+        w1.close()
     stats = opt.stats()
     gate = opt.check_feasible()          # printConstraintsSituations over the batch (untimed; a few milliseconds)
     abytes = algorithmic_bytes(stats, n_pieces)
@@ -237,6 +253,7 @@ def main():
             "p99_evals_per_traj": float(np.percentile(stats[:, 2] + stats[:, 5], 99)),
             "setup_seconds_untimed": setup_s,
             "esdf_build_ms_gpu_untimed": edt_ms,
+            "config1_latency": cfg1,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
