@@ -10,6 +10,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef TOPAY_CPU_EMU
+extern __shared__ double topay_edt_smem[];
+#define TOPAY_EDT_LDS topay_edt_smem
+#else
+#define TOPAY_EDT_LDS ((double*)hip_emu::S().dyn_smem)
+#endif
+
 namespace topay {
 
 struct EdtPass {
@@ -26,56 +33,76 @@ struct EdtPass {
 
 // SRC 0: occupancy bytes, value = ((occ == 1) == (pass == 0)) ? 0 : DMAX ; SRC 1: doubles
 // FIN 0: store the squared distance ; FIN 1: dd = res * sqrt(val); pass 0: out = dd ; pass 1: if (dd > 0) out += res - dd
-template <int SRC, int FIN>
+// WS  0: envelope stacks in the HBM workspace ; WS 1: in LDS (dynamic shared memory: z [n+2][64] doubles followed by
+//        v [n+2][64] 16-bit indices, entry k of lane l at [k][l]: conflict-free), for lines of up to ~250 cells
+template <int SRC, int FIN, int WS>
 __global__ void k_edt_pass(EdtPass P, const signed char* occ, const double* src, double* dst, int* vws, double* zws, int pass,
                            double res) {
+  double* edt_lds = TOPAY_EDT_LDS;  // dynamic shared memory of the block
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (line >= P.nlines) return;
+  const bool live = line < P.nlines;
   const long long mo = (long long)blockIdx.y * P.map_stride;
   if (SRC == 0) occ += mo; else src += mo;
   dst += mo;
-  vws += (long long)blockIdx.y * P.ws_stride;
-  zws += (long long)blockIdx.y * P.ws_stride;
-  const long long base = (line / P.inner) * P.outer_stride + (line % P.inner) * P.inner_stride;
-  const long long L = P.nlines;
+  const long long lc = live ? line : P.nlines - 1;   // idle lanes of the last block shadow the last line (no stores)
+  const long long base = (lc / P.inner) * P.outer_stride + (lc % P.inner) * P.inner_stride;
+  const int n = P.n;
+  // stack accessors
+  long long L;
+  int* vg = nullptr;
+  double* zg = nullptr;
+  double* zl = nullptr;
+  unsigned short* vl = nullptr;
+  if (WS == 0) {
+    L = P.nlines;
+    vg = vws + (long long)blockIdx.y * P.ws_stride + lc;
+    zg = zws + (long long)blockIdx.y * P.ws_stride + lc;
+  } else {
+    L = 64;
+    zl = edt_lds + threadIdx.x;
+    vl = (unsigned short*)(edt_lds + (size_t)(n + 2) * 64) + threadIdx.x;
+  }
+  auto V = [&](int k) -> int { return WS == 0 ? vg[(long long)k * L] : (int)vl[k * 64]; };
+  auto Z = [&](int k) -> double { return WS == 0 ? zg[(long long)k * L] : zl[k * 64]; };
+  auto setV = [&](int k, int q) { if (WS == 0) vg[(long long)k * L] = q; else vl[k * 64] = (unsigned short)q; };
+  auto setZ = [&](int k, double z) { if (WS == 0) zg[(long long)k * L] = z; else zl[k * 64] = z; };
   auto f = [&](int q) -> double {
     const long long a = base + (long long)q * P.step;
     if (SRC == 0) return ((occ[a] == 1) == (pass == 0)) ? 0.0 : TOPAY_EDT_DMAX;
     return src[a];
   };
-  int* v = vws + line;      // v[k] at v[k * L]
-  double* z = zws + line;   // z[k] at z[k * L]
-  const int n = P.n;
   int k = 0;
-  v[0] = 0;
-  z[0] = -TOPAY_EDT_DMAX;
-  z[L] = TOPAY_EDT_DMAX;
+  setV(0, 0);
+  setZ(0, -TOPAY_EDT_DMAX);
+  setZ(1, TOPAY_EDT_DMAX);
   for (int q = 1; q <= n - 1; q++) {
     k++;
     double s;
     const double fq = f(q) + (double)(q * q);
     do {
       k--;
-      const int vk = v[(long long)k * L];
+      const int vk = V(k);
       s = (fq - (f(vk) + (double)(vk * vk))) / (double)(2 * q - 2 * vk);
-    } while (s <= z[(long long)k * L]);
+    } while (s <= Z(k));
     k++;
-    v[(long long)k * L] = q;
-    z[(long long)k * L] = s;
-    z[(long long)(k + 1) * L] = TOPAY_EDT_DMAX;
+    setV(k, q);
+    setZ(k, s);
+    setZ(k + 1, TOPAY_EDT_DMAX);
   }
   k = 0;
   for (int q = 0; q <= n - 1; q++) {
-    while (z[(long long)(k + 1) * L] < (double)q) k++;
-    const int vk = v[(long long)k * L];
+    while (Z(k + 1) < (double)q) k++;
+    const int vk = V(k);
     const double val = (double)((q - vk) * (q - vk)) + f(vk);
     const long long a = base + (long long)q * P.step;
-    if (FIN == 0) {
-      dst[a] = val;
-    } else {
-      const double dd = res * sqrt(val);
-      if (pass == 0) dst[a] = dd;
-      else if (dd > 0.0) dst[a] += (-dd + res);
+    if (live) {
+      if (FIN == 0) {
+        dst[a] = val;
+      } else {
+        const double dd = res * sqrt(val);
+        if (pass == 0) dst[a] = dd;
+        else if (dd > 0.0) dst[a] += (-dd + res);
+      }
     }
   }
 }

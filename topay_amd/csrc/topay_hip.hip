@@ -586,26 +586,40 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
   int* vws = c->edt_v.as<int>();
   double* zws = c->edt_z.as<double>();
   const double res = desc->resolution;
-  auto launch = [&](auto kern, EdtPass P, long long map_stride, const signed char* occ, const double* src, double* dst, int pass) {
+  // envelope stacks in LDS when a 64-line block fits ((n + 2) x 64 x (8 + 2) B <= 150 KB, i.e. lines up to ~238 cells)
+  // and the launch is small, else in the HBM workspace
+  auto lds_bytes = [](int n) { return (size_t)(n + 2) * 64 * 10; };
+  auto launch = [&](auto kern_g, auto kern_l, EdtPass P, long long map_stride, const signed char* occ, const double* src,
+                    double* dst, int pass) -> topay_status {
     const int bs = 64;
     P.map_stride = map_stride;
     P.ws_stride = (long long)ws_elems;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((P.nlines + bs - 1) / bs), (unsigned)n_maps), dim3(bs), 0, c->stream, P, occ, src, dst,
-                       vws, zws, pass, res);
+    const dim3 grid((unsigned)((P.nlines + bs - 1) / bs), (unsigned)n_maps);
+    const size_t lb = lds_bytes(P.n);
+    // LDS stacks cut the latency of every envelope step but leave one wave per CU resident (129 KB per 64-line block
+    // at n = 200): they win while the launch cannot fill the device anyway (a single benchmark-size map: 2.7 vs 3.8 ms)
+    // and lose when there are lines enough to hide the HBM latency instead (1024 maps: 191 vs 142 ms).
+    if (lb <= 56 * 1024 || (lb <= 150 * 1024 && (long long)n_maps * P.nlines <= 65536)) {  // short lines: several blocks per CU still fit
+      HIPCHK(hipFuncSetAttribute((const void*)kern_l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+      hipLaunchKernelGGL(kern_l, grid, dim3(bs), lb, c->stream, P, occ, src, dst, vws, zws, pass, res);
+    } else {
+      hipLaunchKernelGGL(kern_g, grid, dim3(bs), 0, c->stream, P, occ, src, dst, vws, zws, pass, res);
+    }
+    return TOPAY_OK;
   };
   for (int pass = 0; pass < 2; pass++) {
     // 3-D: along z (lines (x, y)), along y (lines (x, z)), along x (lines (y, z)) — grid_map.cpp:425-521
     EdtPass pz{(long long)nx * ny, nz, (long long)nx * ny, 0, (long long)nz, 1, 0, 0};
     EdtPass py{(long long)nx * nz, ny, (long long)nz, (long long)ny * nz, 1, (long long)nz, 0, 0};
     EdtPass px{(long long)ny * nz, nx, (long long)ny * nz, 0, 1, (long long)ny * nz, 0, 0};
-    launch(k_edt_pass<0, 0>, pz, (long long)n3, d_occ3, nullptr, t1, pass);
-    launch(k_edt_pass<1, 0>, py, (long long)n3, nullptr, t1, t2, pass);
-    launch(k_edt_pass<1, 1>, px, (long long)n3, nullptr, t2, e3, pass);
+    if ((s = launch(k_edt_pass<0, 0, 0>, k_edt_pass<0, 0, 1>, pz, (long long)n3, d_occ3, nullptr, t1, pass)) != TOPAY_OK) return s;
+    if ((s = launch(k_edt_pass<1, 0, 0>, k_edt_pass<1, 0, 1>, py, (long long)n3, nullptr, t1, t2, pass)) != TOPAY_OK) return s;
+    if ((s = launch(k_edt_pass<1, 1, 0>, k_edt_pass<1, 1, 1>, px, (long long)n3, nullptr, t2, e3, pass)) != TOPAY_OK) return s;
     // 2-D: along y (lines x), along x (lines y) — grid_map.cpp:125-207
     EdtPass qy{(long long)nx, ny, (long long)nx, 0, (long long)ny, 1, 0, 0};
     EdtPass qx{(long long)ny, nx, (long long)ny, 0, 1, (long long)ny, 0, 0};
-    launch(k_edt_pass<0, 0>, qy, (long long)n2, d_occ2, nullptr, t1, pass);
-    launch(k_edt_pass<1, 1>, qx, (long long)n2, nullptr, t1, e2, pass);
+    if ((s = launch(k_edt_pass<0, 0, 0>, k_edt_pass<0, 0, 1>, qy, (long long)n2, d_occ2, nullptr, t1, pass)) != TOPAY_OK) return s;
+    if ((s = launch(k_edt_pass<1, 1, 0>, k_edt_pass<1, 1, 1>, qx, (long long)n2, nullptr, t1, e2, pass)) != TOPAY_OK) return s;
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev1, c->stream));
