@@ -1198,7 +1198,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     // belong to this pass, three at a time with every LDS operand fetched before the arithmetic starts (a single
     // wave per SIMD has no other way to overlap the LDS latency); sample order and the arithmetic per sample are
     // unchanged, padding samples of the last chunk are masked.
-    double rbh[RMAX][3];  // hs-powers of each row of this lane (basis_k(k, hs)), also used by the rare round below
+    double rbh[RMAX][3] = {};  // hs-powers of each row of this lane (basis_k(k, hs)), also used by the rare round below
     constexpr int NV = (STAGE == 2) ? 13 : 6;
 #pragma unroll
     for (int v = 0; v < 5; v++) pbuf[v * 64 + lane] = gB[v];
