@@ -272,3 +272,52 @@ def test_config3_full_size_properties():
     ok2 = opt.optimizeTraj(lens, paths)
     assert (ok2 == ok).all() and (opt.traj_cost[ok] == cost[ok]).all() and (opt.stats() == st).all()
     w.close()
+
+
+def test_eval_parity_every_bucket_multi_map():
+    """Per-evaluation parity HIP vs oracle over every N bucket (rows per lane 1, 2 and 3), three kinds of points
+    (initial guess, random perturbation, rare-path trigger), both stages, every candidate against its own map."""
+    tb = wl.TablesBatch(128, 8, base_seed=7000, nthreads=0)
+    opt = api.MomaTrajOptBatch(device=0)
+    views = {}
+    slot = {}
+    for k, s in enumerate(tb.scenarios):
+        w = tb.world(s)
+        set_map(opt, w, map_id=k)
+        slot[s] = k
+        views[s] = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+    opt.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+    N = opt.n_pieces()
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    rng = np.random.default_rng(1)
+    buckets_seen = 0
+    for lo, hi in ((3, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32)):
+        idx = np.nonzero((N >= lo) & (N <= hi))[0]
+        if len(idx) == 0:
+            continue
+        buckets_seen += 1
+        for b in rng.choice(idx, size=min(6, len(idx)), replace=False):
+            b = int(b)
+            o = orc.Oracle(views[int(tb.scen[b])])
+            n = o.set_init_traj(tb.paths[offs[b]:offs[b + 1]])
+            Nb = o.N
+            for trial in range(3):
+                x = o.get_x().copy()
+                if trial == 1:
+                    x += 0.08 * rng.standard_normal(n)
+                if trial == 2:
+                    x[:Nb] -= 1.5
+                    x[Nb - 1] += 2.2
+                    x[3 * Nb - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], Nb - 1)
+                lam, rho = rng.uniform(-1, 1, 2), np.array([1e4, 3e5])
+                o.set_alm(lam, rho)
+                for stage in (1, 2):
+                    f, g = o.eval(stage, x)
+                    if not np.isfinite(f):
+                        continue
+                    fg, gg, _ = opt.eval(stage, b, x, lam, rho)
+                    assert abs(f - fg) <= 1e-11 * abs(f)
+                    assert np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
+    assert buckets_seen >= 6
+    tb.close()
