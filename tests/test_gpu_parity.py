@@ -321,3 +321,35 @@ def test_eval_parity_every_bucket_multi_map():
                     assert np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
     assert buckets_seen >= 6
     tb.close()
+
+
+def test_capped_solves_of_long_trajectories_are_bit_identical_to_emulator():
+    """Rows-per-lane 2 and 3 code paths (N in 14..21 and 22..32): stage 1 plus ten stage-2 iterations, GPU vs the CPU
+    lane emulator, every bit (a full solve of such a trajectory takes minutes in the emulator)."""
+    tb = wl.TablesBatch(128, 8, base_seed=7000, nthreads=0)
+    probe = api.MomaTrajOptBatch(device=0)
+    w0 = tb.world(tb.scenarios[0])
+    set_map(probe, w0)
+    probe.set_init_traj(tb.lens, tb.paths)       # piece counts only depend on the paths
+    N = probe.n_pieces()
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    picks = [int(np.nonzero((N >= lo) & (N <= hi))[0][0]) for lo, hi in ((14, 21), (22, 32))]
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 10
+    p.alm_max_outer = 1
+    for b in picks:
+        w = tb.world(int(tb.scen[b]))
+        path = tb.paths[offs[b]:offs[b + 1]]
+        res = []
+        for lib in (None, EMU_LIB):
+            opt = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+            set_map(opt, w)
+            opt.set_init_traj(np.array([len(path)], dtype=np.int32), path)
+            opt.set_trace(200)
+            ok = opt.optimize()
+            res.append((ok.copy(), opt.traj_cost.copy(), opt.stats(), opt.get_trace(0), opt.get_x(0)))
+        g, e = res
+        assert (g[0] == e[0]).all() and (g[2] == e[2]).all() and (g[3] == e[3]).all() and (g[4] == e[4]).all()
+        assert (g[1] == e[1]).all() or (np.isnan(g[1]).all() and np.isnan(e[1]).all())
+        assert g[2][0, 5] >= 10
+    tb.close()
