@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] latency figure (profiling runs)")
     ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
                     help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
                          "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
@@ -188,7 +189,7 @@ def main():
     # BASELINE configs[1] (one tables scenario x 64 candidates) as a latency figure beside the throughput line: the batch
     # is far too small to fill the device (64 wavefronts), so its time is the longest candidate's.
     cfg1 = None
-    if rank == 0 and not hires:
+    if rank == 0 and not hires and not args.no_config1:
         w1, _, _, lens1, paths1 = wl.tables_scenario(0, 64)
         o1 = api.MomaTrajOptBatch(device=local_rank)
         o1.set_map(w1.origin, w1.res, w1.dims, w1.min_b, w1.max_b, w1.esdf2d, w1.esdf3d)

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1"   # strictly serial steps: clean per-step spans
+ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1"   # strictly serial steps: clean per-step spans
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/bench_kt.json 2> $OUT/kt.log
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log

@@ -20,7 +20,7 @@ def main(src, dst, tag):
     out = []
     kt = os.path.join(src, "kt", "kt_results.db")
     cols, rows = q(kt, "select name, total_calls, total_duration, average, percentage from top_kernels")
-    out.append(f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1")
+    out.append(f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1")
     out.append("")
     out.append("## Kernel statistics (durations in microseconds)")
     out.append("")
