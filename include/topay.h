@@ -201,8 +201,9 @@ topay_status topay_get_stats(topay_ctx* ctx, int* stats /* batch x 8 */);
 
 /* Per-candidate optimisation time in microseconds, measured on the device (the reference logs the same quantity per
  * candidate, planner.cpp:893-905 "optimization time").  start_us (optional): when each solve started, on the same
- * device clock (only differences are meaningful).  Either pointer may be NULL. */
-topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */);
+ * device clock (only differences are meaningful); hw_id (optional): the hardware slot it ran on,
+ * xcc << 16 | se << 12 | cu << 4 | simd (scheduling diagnostics).  Any pointer may be NULL. */
+topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double* start_us /* batch */, int* hw_id /* batch */);
 
 /* == GridMap::isWholeBodyCollision (src/map/include/map/grid_map.h:613-650) for n states (x, y, theta, q1..q7) against
  * map slot map_id: collide[i] = 1 when state i violates a joint limit, lies outside the map or collides (chassis, the 12

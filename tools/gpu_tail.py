@@ -56,3 +56,11 @@ for i in range(20):
     occ.append(int(round(overlap)))
 print("span ms %.0f; mean resident waves per 5%% time bin:" % (T / 1e3), occ)
 np.savez("gpurun_out/tail_data.npz", N=N, lens=tb.lens, evals=ev, ok=ok, us=us, start=su, st=st, scen=tb.scen)
+
+hw = opt.hw_ids()[launched]
+slots = np.unique(hw)
+print("distinct SIMD slots used:", len(slots), " XCCs", len(np.unique(hw >> 16)), " CUs", len(np.unique(hw >> 4)))
+busy = np.array([us[launched][hw == h_].sum() for h_ in slots]) / 1e6
+print("busy seconds per used SIMD slot: min %.2f median %.2f max %.2f (span %.2f s)" % (busy.min(), np.median(busy), busy.max(), T / 1e6))
+percu = np.bincount((np.unique(hw) >> 4) - (np.unique(hw) >> 4).min())
+print("SIMDs used per CU histogram:", np.bincount(np.bincount(np.unique(hw) >> 4)[np.bincount(np.unique(hw) >> 4) > 0]))

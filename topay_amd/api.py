@@ -97,7 +97,7 @@ def load(path=None):
     L.topay_get_total_durations.argtypes = [C.c_void_p, c_dp]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
     L.topay_feasibility_report.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
-    L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp]
+    L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp, c_ip]
     L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
@@ -315,13 +315,18 @@ class MomaTrajOptBatch:
     def elapsed_us(self):
         """Device-measured optimisation time of every candidate (microseconds)."""
         t = np.zeros(self.batch)
-        _chk(self.L, self.L.topay_get_elapsed_us(self.h, _dp(t), None))
+        _chk(self.L, self.L.topay_get_elapsed_us(self.h, _dp(t), None, None))
         return t
 
     def start_us(self):
         t = np.zeros(self.batch)
-        _chk(self.L, self.L.topay_get_elapsed_us(self.h, None, _dp(t)))
+        _chk(self.L, self.L.topay_get_elapsed_us(self.h, None, _dp(t), None))
         return t - t.min()
+
+    def hw_ids(self):
+        h = np.zeros(self.batch, dtype=np.int32)
+        _chk(self.L, self.L.topay_get_elapsed_us(self.h, None, None, _ip(h)))
+        return h
 
     def get_x(self, i):
         n = C.c_int(0)

@@ -144,6 +144,15 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     Bt.alm[4 * b] = C.lam0; Bt.alm[4 * b + 1] = C.lam1; Bt.alm[4 * b + 2] = C.rho0; Bt.alm[4 * b + 3] = C.rho1;
     Bt.elapsed_us[b] = (double)(wall_clock64() - t_begin) * 0.01;
     Bt.start_us[b] = (double)t_begin * 0.01;
+#ifndef TOPAY_CPU_EMU
+    {
+      const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+      const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
+      Bt.hw_id[b] = (int)(((xcc & 0xF) << 16) | (((hw >> 13) & 0x7) << 12) | (((hw >> 8) & 0xF) << 4) | ((hw >> 4) & 0x3));
+    }
+#else
+    Bt.hw_id[b] = 0;
+#endif
   }
 }
 
@@ -303,7 +312,7 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, hwid, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
   float last_edt_ms = 0.f;
   int trace_cap = 0;
   DevBatch db;
@@ -486,7 +495,7 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
@@ -771,6 +780,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(fout, (size_t)batch * 8);
   ENS(elapsed, (size_t)batch * 8);
   ENS(startus, (size_t)batch * 8);
+  ENS(hwid, (size_t)batch * 4);
 #undef ENS
   d.Nmax = Nmax; d.nmax = c->nmax; d.hist_m = m;
   d.x = c->x.as<double>(); d.work = c->work.as<double>();
@@ -782,6 +792,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.knots = c->knots.as<double>(); d.alm = c->alm.as<double>(); d.fout = c->fout.as<double>();
   d.elapsed_us = c->elapsed.as<double>();
   d.start_us = c->startus.as<double>();
+  d.hw_id = c->hwid.as<int>();
   HIPCHK(hipMemset(c->elapsed.p, 0, (size_t)batch * 8));
   HIPCHK(hipMemset(c->success.p, 0, (size_t)batch * 4));
   HIPCHK(hipMemset(c->stats.p, 0, (size_t)batch * 32));
@@ -891,11 +902,12 @@ topay_status topay_get_batch(topay_ctx* c, int* success, double* cost, int* n_pi
   return TOPAY_OK;
 }
 
-topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us) {
+topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us, int* hw_id) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   if (us) HIPCHK(hipMemcpy(us, c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   if (start_us) HIPCHK(hipMemcpy(start_us, c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (hw_id) HIPCHK(hipMemcpy(hw_id, c->hwid.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 

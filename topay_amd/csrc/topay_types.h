@@ -104,6 +104,7 @@ struct DevBatch {
   double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
   double* fout;       // [B] eval hook output
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
+  int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
   double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
   const int* order;   // [B] block -> trajectory map
   double* trace;      // optional [B][trace_cap] f of every evaluation (debug / parity tooling), may be null
