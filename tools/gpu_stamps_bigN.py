@@ -26,7 +26,7 @@ gpu.set_init_traj(lens, paths, map_ids=map_ids[sel])
 gpu.set_trace(64)
 ok = gpu.optimize(); ms, nl = gpu.last_kernel_ms()
 st = gpu.stats(); ev = (st[:, 2] + st[:, 5]).astype(float)
-names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 round A)"]
+names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]
 tot = np.zeros(16)
 for b in range(len(lens)):
     tot += gpu.get_trace(b)[8:24].view(np.int64)[:16].astype(float)

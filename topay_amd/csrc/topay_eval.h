@@ -567,13 +567,9 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   lds_sync();
   STAMP(C, 1);  // LU
   // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118 (one lane per column)
-  {
-    SUBSTAMP_BEGIN(C);
-    if (lane < 9) {
-      band_sweep<0>(cL + lane * rows, band, rdiag, rows);
-      band_sweep<1>(cL + lane * rows, band, rdiag, rows);
-    }
-    SUBSTAMP_END(C, 9);  // (diagnostic experiment: folded into slot 9)
+  if (lane < 9) {
+    band_sweep<0>(cL + lane * rows, band, rdiag, rows);
+    band_sweep<1>(cL + lane * rows, band, rdiag, rows);
   }
   // stash LU + reciprocal diagonal for the adjoint solve
   for (int t = lane; t < 14 * rows; t += 64) c_lu[t] = c_X[t];
@@ -1047,9 +1043,6 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 
   // =========================== sweep 1: forward over even samples ===========================
   for (int pass = 0; pass < npass; pass++) {
-#ifdef TOPAY_STAMPS
-    const long long pro_t0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
     const int e = pass * 64 + lane;
     const bool act = e < NE;
     const int i = act ? e / TOPAY_EP : N - 1;
@@ -1084,7 +1077,6 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
     bool jva = false;
 #ifdef TOPAY_STAMPS
-    (void)pro_t0_;
 #endif
     SUBSTAMP_BEGIN(C);
     if (act) {
