@@ -1481,7 +1481,20 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   lds_dp band = c_X;
   lds_dp rdiag = c_X + 13 * rows;
   lds_dp adj = C.gC;             // [9][rows]: the adjoint solve runs in place on the dJ/dC accumulator
-  for (int t = lane; t < 14 * rows; t += 64) c_X[t] = c_lu[t];
+  // reload of the LU factors, eight loads in flight per lane (a plain strided loop is serialised load by load)
+  for (int t0 = lane; t0 < 14 * rows; t0 += 64 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + 64 * u;
+      v[u] = c_lu[t < 14 * rows ? t : 14 * rows - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + 64 * u;
+      if (t < 14 * rows) c_X[t] = v[u];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
     if (ract[r]) {
