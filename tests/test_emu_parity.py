@@ -186,3 +186,44 @@ def test_edge_case_inputs_follow_the_oracle():
     assert emu.n_pieces()[0] == o.N == 23
     assert np.allclose(emu.get_x(0), o.get_x(), rtol=0, atol=1e-12)
     w.close()
+
+
+def test_optimizer_yaml_parameters_are_wired_not_hard_coded(cuboids_small):
+    """Every weight of optimizer.yaml that the oracle lets a test change is changed (one at a time, by an odd factor) in
+    both implementations: the kernel's cost and gradient must follow the oracle's, and must actually move."""
+    cs = cuboids_small
+    b = 3
+    path = cs["paths"][cs["offs"][b]:cs["offs"][b + 1]]
+    names = ["relu_mu", "s1_time_weight", "s1_moment_weight", "s1_acc_weight", "s1_domega_weight", "s1_path_pos_weight",
+             "s2_time_weight", "s2_moment_weight", "s2_acc_weight", "s2_domega_weight", "s2_collision_weight",
+             "s2_mani_colli_weight", "s2_self_colli_weight", "s2_mani_pos_weight", "s2_mani_vel_weight", "s2_mani_acc_weight",
+             "s2_mean_time_weight"]
+    base = api.default_params()
+    o0 = orc.Oracle(cs["map"])
+    n = o0.set_init_traj(path)
+    N = o0.N
+    x = o0.get_x().copy()
+    x[:N] -= 1.6                       # short durations: velocity / acceleration / joint-rate penalties are active
+    x[N - 1] += 2.5                    # and one long piece: the mean-time band
+    x[3 * N - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], N - 1)   # folded arm: joint limits, self collision
+    lam, rho = [0.3, -0.2], [1e4, 2e4]
+    o0.set_alm(lam, rho)
+    f_base = {s: o0.eval(s, x)[0] for s in (1, 2)}
+    moved = 0
+    for name in names:
+        p = api.default_params()
+        setattr(p, name, getattr(base, name) * 1.37)
+        emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+        set_map(emu, cs["world"])
+        emu.set_init_traj(cs["lens"][b:b + 1], path)
+        o = orc.Oracle(cs["map"])
+        o.set_param(name, getattr(base, name) * 1.37)
+        o.set_init_traj(path)
+        o.set_alm(lam, rho)
+        stage = 1 if name.startswith("s1_") else 2
+        f, g = o.eval(stage, x)
+        fe, ge, _ = emu.eval(stage, 0, x, lam, rho)
+        assert abs(f - fe) <= 1e-11 * abs(f) and np.abs(g - ge).max() <= 1e-10 * np.abs(g).max(), name
+        if abs(f - f_base[stage]) > 1e-9 * abs(f):
+            moved += 1
+    assert moved >= len(names) - 2     # at this point nearly every term is active
