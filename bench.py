@@ -82,7 +82,9 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    distributed = world > 1
+    # TOPAY_FORCE_DIST=1: take the multi-rank code path (RCCL init, record gather, reductions) with a single rank too,
+    # so that it can be validated on a one-GPU box
+    distributed = world > 1 or (os.environ.get("TOPAY_FORCE_DIST") == "1" and "RANK" in os.environ)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -265,7 +267,7 @@ def main():
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not hires:
+    if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline and not hires:
         # CPU baseline: the oracle (a C++ port of the reference path; the reference itself needs Eigen/ROS/Boost and
         # cannot be built here) on the host cores of this box.  One pool of worker threads, one trajectory per task,
         # every trajectory against its own scenario's map; bounded sample = the first `cpu_sample` trajectories.
