@@ -20,6 +20,9 @@ import os
 import sys
 import time
 
+# before anything initialises HIP (torch.cuda does): the solver's bucket streams need distinct hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -264,6 +264,7 @@ inline hipError_t hipMemcpyToSymbolAsync(void* sym, const void* src, size_t n, s
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
 #define hipStreamNonBlocking 1
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu(); return 0; }

@@ -276,14 +276,21 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
-#define TOPAY_NBUCKET 7
-// launch buckets by number of pieces: upper bounds (inclusive); rows per lane = 1 / 1 / 2 / 2 / 2 / 3 / 3.
-// Each bucket has its own stream.  HIP maps streams of one priority onto a pool of 4 hardware queues shared with
-// every other stream of the process, and streams that share a queue serialise (measured: tools/queue_probe.hip),
-// so the buckets are spread over the three priority levels -- at most three per level (the normal level also carries the context's own two streams and the null stream) -- with the longest
-// trajectories on the highest priority: their workgroups are dispatched first, which is what the tail needs.
-static const int kBucketMaxN[TOPAY_NBUCKET] = {7, 10, 13, 16, 21, 26, 32};
-static const int kBucketPrio[TOPAY_NBUCKET] = {+1, +1, +1, 0, -1, -1, -1};  // -1 greatest ... +1 least
+#define TOPAY_NBUCKET 3
+// Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3).
+// Each bucket is one launch on its own stream so that the three run concurrently.  All streams have the SAME priority:
+// mixed priorities made the hardware preempt (context-save) the low-priority waves whenever high-priority work
+// arrived, and twice in ~80 runs one low-priority launch was starved for tens of seconds.  HIP maps the streams of one
+// priority onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues shared by every stream of the process, and
+// streams that share a queue serialise (tools/queue_probe.hip); the library asks for 8 queues at load time (below)
+// when the environment does not say otherwise.  With one wave per SIMD, LDS (<= 20 / 36 / 53 KB per wave) is not
+// what limits residency, so finer buckets would buy nothing.
+static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32};
+
+// Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
+// (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
+// GPU_MAX_HW_QUEUES=8 itself.
+__attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 #define TOPAY_MAX_DEVICES 16
 static hipStream_t g_bucket_streams[TOPAY_MAX_DEVICES][TOPAY_NBUCKET] = {};
 static std::mutex g_bucket_mutex;
@@ -476,8 +483,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     std::lock_guard<std::mutex> lk(g_bucket_mutex);
     for (int k = 0; k < topay_ctx::NBUCKET; k++)
       if (!g_bucket_streams[dev_slot][k])
-        HIPCHK(hipStreamCreateWithPriority(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking,
-                                           getenv("TOPAY_FLAT_PRIORITY") ? 0 : kBucketPrio[k]));
+        HIPCHK(hipStreamCreateWithFlags(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking));
   }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     c->bstream[k] = g_bucket_streams[dev_slot][k];
