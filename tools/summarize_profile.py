@@ -32,7 +32,7 @@ def main(src, dst, tag):
                        "accum_vgpr_count, sgpr_count from kernels where name like 'k_solve%' order by start")
     t0 = rows[0][2]
     out.append("")
-    out.append("## Solve-kernel dispatches (one per N-bucket, concurrent on prioritised streams)")
+    out.append("## Solve-kernel dispatches (one per N-bucket, concurrent on three same-priority streams)")
     out.append("")
     out.append("| kernel | queue | start ms | duration ms | trajectories | LDS B | scratch B/lane | arch VGPR | AGPR | SGPR |")
     out.append("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
