@@ -353,3 +353,36 @@ def test_capped_solves_of_long_trajectories_are_bit_identical_to_emulator():
         assert (g[1] == e[1]).all() or (np.isnan(g[1]).all() and np.isnan(e[1]).all())
         assert g[2][0, 5] >= 10
     tb.close()
+
+
+def test_two_batches_in_flight_give_the_serial_results():
+    """topay_optimize_async / topay_synchronize: two contexts issued back to back on one GPU return exactly what a
+    serial solve returns (no cross-talk through the shared bucket streams or the shared parameter block)."""
+    tb = wl.TablesBatch(16, 8, base_seed=4242, nthreads=8)
+    half = len(tb.lens) // 2
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    parts = [(tb.lens[:half], tb.paths[:offs[half]], tb.scen[:half]), (tb.lens[half:], tb.paths[offs[half]:], tb.scen[half:])]
+
+    def make(part):
+        lens, paths, scen = part
+        o = api.MomaTrajOptBatch(device=0)
+        slot = {}
+        for s in sorted(set(scen.tolist())):
+            slot[s] = len(slot)
+            set_map(o, tb.world(s), map_id=slot[s])
+        o.set_init_traj(lens, paths, map_ids=np.array([slot[s] for s in scen], dtype=np.int32))
+        return o
+
+    serial = []
+    for part in parts:
+        o = make(part)
+        ok = o.optimize()
+        serial.append((ok.copy(), o.traj_cost.copy(), o.stats()))
+    a, b = make(parts[0]), make(parts[1])
+    a.optimize_async()
+    b.optimize_async()
+    res = [(a.finish(), a.traj_cost.copy(), a.stats()), (b.finish(), b.traj_cost.copy(), b.stats())]
+    for (ok_s, c_s, st_s), (ok_p, c_p, st_p) in zip(serial, res):
+        assert (ok_s == ok_p).all() and (st_s == st_p).all()
+        assert ((c_s == c_p) | (np.isnan(c_s) & np.isnan(c_p))).all()
+    tb.close()
