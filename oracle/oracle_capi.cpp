@@ -136,6 +136,7 @@ void orc_get_stats(void* hh, int s[8]) {
   s[0] = st.stage1_ret; s[1] = st.stage1_iters; s[2] = st.stage1_evals; s[3] = st.stage2_last_ret;
   s[4] = st.stage2_iters; s[5] = st.stage2_evals; s[6] = st.alm_outer; s[7] = st.sum_bound;
 }
+void orc_debug_counters(long long* out2) { out2[0] = g_dbg_ls_evals; out2[1] = g_dbg_ftest_fail; }
 double orc_traj_cost(void* hh) { return ((OracleHandle*)hh)->opt.traj_cost; }
 void orc_get_traj(void* hh, double* durations, double* coeffs, double* knots_xy) {
   ((OracleHandle*)hh)->opt.getTraj(durations, coeffs, knots_xy);
