@@ -323,6 +323,8 @@ struct EvalCtx {
   lds_dp gdT;    // [N]        penalty dJ/dT accumulator
   lds_dp pcs;    // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
   lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
+  glb_dp sbuf;   // HBM [14][sb_stride]: per-sample gradient rows parked between the cost and the gradient phase
+  int sb_stride;
   lds_dp pw;     // [26][6]    integer powers jj^k of the Simpson sample index (constant for the whole solve)
   lds_dp X;      // union region: band + reciprocal diagonal (14*rows) | sample buffers (26N + 960)
   // global
@@ -391,6 +393,23 @@ __device__ __forceinline__ void fill_power_table(lds_dp pw, int lane) {
 #define SUBSTAMP_BEGIN(C) do { } while (0)
 #define SUBSTAMP_END(C, k) do { } while (0)
 #endif
+
+// Decides, once the cost of an evaluation is known, whether its gradient will be used.  In the reference's line search
+// (lbfgs.hpp:318-340) a trial that fails the sufficient-decrease test is discarded without its gradient ever being
+// read (the next trial overwrites it, an error exit restores the previous one), and that is 37 % of all evaluations:
+// for those the gradient phase -- row accumulation, sweep 2, adjoint solve, assembly -- is skipped.  The decision
+// uses the same expressions as the line search itself, so the iteration is unchanged.
+struct GradGate {
+  bool always;      // first evaluation of a run, test hooks
+  bool has_early;   // past > 0
+  double finit, thr /* finit + stp * dgtest */, early /* delta / past */;
+  __device__ __forceinline__ bool needs(double f) const {
+    if (always) return true;
+    if (isinf(f) || isnan(f)) return false;                                        // INVALID_FUNCVAL: reverted
+    if (has_early && fabs(finit - f) / (fabs(finit) + 1.0) < early) return true;   // early accept
+    return !(f > thr);                                                             // else: needs g . d
+  }
+};
 
 // Banded triangular sweeps with one lane per right-hand side (banded_system.hpp:96-118 and 123-145).
 // The reference's substitutions are column sweeps: step j finalises x(j) and updates the six following (or
@@ -973,7 +992,7 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 // RMAX = system rows per lane (1: N <= 10, 2: N <= 21, 3: N <= 32).  Returns f (wave-uniform); writes g[n].
 // ---------------------------------------------------------------------------------------------
 template <int STAGE, int RMAX>
-__device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp) {
+__device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
   // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
   // is a flat (generic address space) load that the compiler must repeat after every LDS store.
   const lds_dp c_Tp = C.Tp;
@@ -1178,12 +1197,110 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       cost_pen += cst;
     }
     SUBSTAMP_END(C, 12);  // sample body of lane 0
-#ifdef TOPAY_STAMPS
-    const long long rnd_t0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
     if (act) {
       gxy[2 * e] = gpx;
       gxy[2 * e + 1] = gpy;
+    }
+    // ---- park the per-sample gradient rows in HBM ([value][sample], coalesced): whether they are needed is only known
+    // once the cost of the whole trajectory is (GradGate)
+    if (act) {
+      glb_dp sb = C.sbuf + e;
+      const int ss = C.sb_stride;
+#pragma unroll
+      for (int v = 0; v < 5; v++) sb[v * ss] = gB[v];
+      sb[5 * ss] = gdTs;
+      if (STAGE == 2) {
+#pragma unroll
+        for (int v = 0; v < 7; v++) sb[(6 + v) * ss] = gB[5 + v];
+        sb[13 * ss] = jva ? 1.0 : 0.0;
+      }
+    }
+  }
+
+  STAMP(C, 4);  // sweep 1
+  // ---- per-piece terms between the sweeps
+  double cost_piece = 0.0;
+  double chain0x = 0.0, chain0y = 0.0;  // constant added to every chain entry (ALM term)
+  double mt_add_all = 0.0, mt_add_own = 0.0;
+  if (STAGE == 1) {
+    // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
+    lds_sync();
+    if (lane < N) {
+      const double ex = c_pcs[2 * N + 2 * (lane + 1)] - c_init_xy[2 * lane];
+      const double ey = c_pcs[2 * N + 2 * (lane + 1) + 1] - c_init_xy[2 * lane + 1];
+      cost_piece = P.s1_path_pos_weight * (ex * ex + ey * ey);
+      c_pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
+      c_pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
+    }
+    lds_sync();
+  } else {
+    // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
+    const double Tm = lane < N ? c_Tp[lane] : 0.0;
+    const double avg = wave_sum(Tm) / N;
+    double add_all = 0.0, add_own = 0.0;
+    if (lane < N) {
+      const double wMT = P.s2_mean_time_weight;
+      if (Tm < avg * 0.5) {
+        const double dd = Tm - avg * 0.5;
+        cost_piece += wMT * dd * dd;
+        add_all += wMT * 2.0 * dd * (-0.5 / N);
+        add_own += wMT * 2.0 * dd;
+      }
+      if (Tm > avg * 2.0) {
+        const double dd = Tm - avg * 2.0;
+        cost_piece += wMT * dd * dd;
+        add_all += wMT * 2.0 * dd * (-2.0 / N);
+        add_own += wMT * 2.0 * dd;
+      }
+    }
+    mt_add_all = add_all;   // their dJ/dT part is added in the gradient phase, after the sample rows (same order as
+    mt_add_own = add_own;   // when both were done in one sweep)
+    // ALM end-point term — moma_traj_opt.cpp:1785-1810
+    C.fxe0 = (c_sx + carryx) - c_ex;
+    C.fxe1 = (c_sy + carryy) - c_ey;
+    const double ea = C.fxe0 + c_lam0 / c_rho0, eb = C.fxe1 + c_lam1 / c_rho1;
+    if (lane == 0) cost_piece += 0.5 * (c_rho0 * (ea * ea) + c_rho1 * (eb * eb));
+    chain0x = c_rho0 * ea;
+    chain0y = c_rho1 * eb;
+  }
+  double penalty_cost = wave_sum(cost_pen + cost_piece);
+  // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
+  const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
+  lds_sync();
+  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
+  const double time_cost = wT * wave_sum(lane < N ? c_Tp[lane] : 0.0);
+  const double f_total = jerk_cost + (bad ? 1.0e+22 : penalty_cost) + time_cost;
+
+  STAMP(C, 5);  // between sweeps
+  // ---- the cost is known: is the gradient going to be read?  (wave-uniform)
+  if (!gate.needs(f_total)) return f_total;
+
+  // =========================== gradient phase ===========================
+  // row accumulation from the parked per-sample rows, pass by pass in the order of sweep 1
+  for (int pass = 0; pass < npass; pass++) {
+#ifdef TOPAY_STAMPS
+    const long long rnd_t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    const int e = pass * 64 + lane;
+    const bool act = e < NE;
+    const int i = act ? e / TOPAY_EP : N - 1;
+    const int m = act ? e - TOPAY_EP * i : 0;
+    const int j = 2 * m;
+    const double step = c_Tp[i] / TOPAY_K, half = step / 2.0;
+    double gB[12], gdTs;
+    bool jva = false;
+    {
+      glb_cdp sb = C.sbuf + (act ? e : NE - 1);
+      const int ss = C.sb_stride;
+      double raw[14];
+#pragma unroll
+      for (int v = 0; v < ((STAGE == 2) ? 14 : 6); v++) raw[v] = sb[v * ss];
+#pragma unroll
+      for (int v = 0; v < 5; v++) gB[v] = act ? raw[v] : 0.0;
+      gdTs = act ? raw[5] : 0.0;
+#pragma unroll
+      for (int v = 0; v < 7; v++) gB[5 + v] = (STAGE == 2 && act) ? raw[6 + v] : 0.0;
+      if (STAGE == 2) jva = act && raw[13] != 0.0;
     }
     // ---- hand the per-sample gradient rows to the row lanes: theta/s rows (orders 0-2), gdT and, in stage 2, the
     // order-0 joint rows, in ONE round.  Row lane (piece pi, power k) accumulates over the samples of its piece that
@@ -1322,57 +1439,11 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #endif
   }
 
-  STAMP(C, 4);  // sweep 1
-  // ---- per-piece terms between the sweeps
-  double cost_piece = 0.0;
-  double chain0x = 0.0, chain0y = 0.0;  // constant added to every chain entry (ALM term)
-  if (STAGE == 1) {
-    // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
-    lds_sync();
-    if (lane < N) {
-      const double ex = c_pcs[2 * N + 2 * (lane + 1)] - c_init_xy[2 * lane];
-      const double ey = c_pcs[2 * N + 2 * (lane + 1) + 1] - c_init_xy[2 * lane + 1];
-      cost_piece = P.s1_path_pos_weight * (ex * ex + ey * ey);
-      c_pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
-      c_pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
-    }
-    lds_sync();
-  } else {
-    // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
-    const double Tm = lane < N ? c_Tp[lane] : 0.0;
-    const double avg = wave_sum(Tm) / N;
-    double add_all = 0.0, add_own = 0.0;
-    if (lane < N) {
-      const double wMT = P.s2_mean_time_weight;
-      if (Tm < avg * 0.5) {
-        const double dd = Tm - avg * 0.5;
-        cost_piece += wMT * dd * dd;
-        add_all += wMT * 2.0 * dd * (-0.5 / N);
-        add_own += wMT * 2.0 * dd;
-      }
-      if (Tm > avg * 2.0) {
-        const double dd = Tm - avg * 2.0;
-        cost_piece += wMT * dd * dd;
-        add_all += wMT * 2.0 * dd * (-2.0 / N);
-        add_own += wMT * 2.0 * dd;
-      }
-    }
-    const double all = wave_sum(add_all);
-    if (lane < N) c_gdT[lane] += all + add_own;
-    // ALM end-point term — moma_traj_opt.cpp:1785-1810
-    C.fxe0 = (c_sx + carryx) - c_ex;
-    C.fxe1 = (c_sy + carryy) - c_ey;
-    const double ea = C.fxe0 + c_lam0 / c_rho0, eb = C.fxe1 + c_lam1 / c_rho1;
-    if (lane == 0) cost_piece += 0.5 * (c_rho0 * (ea * ea) + c_rho1 * (eb * eb));
-    chain0x = c_rho0 * ea;
-    chain0y = c_rho1 * eb;
+  if (STAGE == 2) {  // mean-time band, dJ/dT part — moma_traj_opt.cpp:1752-1769
+    const double all = wave_sum(mt_add_all);
+    if (lane < N) c_gdT[lane] += all + mt_add_own;
   }
-  double penalty_cost = wave_sum(cost_pen + cost_piece);
-  // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
-  const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
   lds_sync();
-
-  STAMP(C, 5);  // between sweeps
   // =========================== sweep 2: backward, XY-gradient chain ===========================
   if (!bad) {
     double rcarryx = chain0x, rcarryy = chain0y;
@@ -1566,14 +1637,9 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     gdT_tot = jerk_gdT + c_gdT[i] + s;
   }
   // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948
-  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
   glb_cdp Tau = c_x;
   glb_cdp Vq = c_x + 3 * N - 1;
-  double tsum = 0.0;
-  if (lane < N) {
-    c_g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
-    tsum = c_Tp[lane];
-  }
+  if (lane < N) c_g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
   for (int t = lane; t < 9 * (N - 1); t += 64) {
     const int i = t / 9, d = t - 9 * i;
     const double gp = adj[d * rows + 6 * i + 5];  // gdP.col(i) = adjGrad.row(6i+5)
@@ -1582,10 +1648,9 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
     else c_g[3 * N - 1 + 7 * i + (d - 2)] = gp * dQdVq(Vq[7 * i + d - 2], P.joint_pos_limit_max[d - 2]);
   }
   if (lane == 0) c_g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
-  const double time_cost = wT * wave_sum(tsum);
   __syncthreads();  // g (global memory) becomes visible to the lanes that read it next
   STAMP(C, 8);  // gradient assembly
-  return jerk_cost + penalty_cost + time_cost;
+  return f_total;
 }
 
 }  // namespace topay

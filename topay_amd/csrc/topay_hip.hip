@@ -59,6 +59,8 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
     C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
   }
   C.lu = (glb_dp)(Bt.lu + (size_t)b * 14 * 6 * Bt.Nmax);
+  C.sb_stride = TOPAY_EP * Bt.Nmax;
+  C.sbuf = (glb_dp)(Bt.sbuf + (size_t)b * 14 * C.sb_stride);
   C.init_xy = (glb_cdp)(Bt.init_xy + (size_t)b * 2 * init_stride_N);
   C.sx = Bt.start_xy[2 * b]; C.sy = Bt.start_xy[2 * b + 1];
   C.ex = Bt.goal_xy[2 * b];  C.ey = Bt.goal_xy[2 * b + 1];
@@ -86,8 +88,10 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
   __syncthreads();
   double f = 0.0;
   for (int r = 0; r < repeats; r++) {
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp);
-    else f = eval_cost_grad<2, RMAX>(C, mp);
+    GradGate gate;
+    gate.always = true; gate.has_early = false; gate.finit = 0.0; gate.thr = 0.0; gate.early = 0.0;
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
+    else f = eval_cost_grad<2, RMAX>(C, mp, gate);
   }
   if (C.lane == 0) {
     Bt.fout[b] = f;
@@ -319,7 +323,7 @@ struct topay_ctx {
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, hwid, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, hwid, sbuf, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
   float last_edt_ms = 0.f;
   int trace_cap = 0;
   DevBatch db;
@@ -501,7 +505,7 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
@@ -784,6 +788,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(knots, (size_t)batch * 2 * (Nmax + 1) * 8);
   ENS(alm, (size_t)batch * 4 * 8);
   ENS(fout, (size_t)batch * 8);
+  ENS(sbuf, (size_t)batch * 14 * TOPAY_EP * Nmax * 8);
   ENS(elapsed, (size_t)batch * 8);
   ENS(startus, (size_t)batch * 8);
   ENS(hwid, (size_t)batch * 4);
@@ -796,6 +801,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.success = c->success.as<int>(); d.cost = c->cost.as<double>(); d.stats = c->stats.as<int>();
   d.xyerr = c->xyerr.as<double>(); d.coef = c->coef.as<double>(); d.T = c->T.as<double>();
   d.knots = c->knots.as<double>(); d.alm = c->alm.as<double>(); d.fout = c->fout.as<double>();
+  d.sbuf = c->sbuf.as<double>();
   d.elapsed_us = c->elapsed.as<double>();
   d.start_us = c->startus.as<double>();
   d.hw_id = c->hwid.as<int>();

@@ -96,8 +96,14 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     __syncthreads();
     STAMP(C, 9);  // L-BFGS bookkeeping between evaluations
     double f;
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp);
-    else f = eval_cost_grad<2, RMAX>(C, mp);
+    GradGate gate;
+    gate.always = (mode == MODE_INIT);
+    gate.has_early = past > 0;
+    gate.finit = finit;
+    gate.thr = finit + stp * dgtest;      // the line search's own expressions (below)
+    gate.early = past > 0 ? lp.delta / past : 0.0;
+    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
+    else f = eval_cost_grad<2, RMAX>(C, mp, gate);
     evals++;
 #ifndef TOPAY_STAMPS
     if (S.trace && lane == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;

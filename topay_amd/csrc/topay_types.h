@@ -103,6 +103,7 @@ struct DevBatch {
   double* knots;      // [B][(Nmax+1)*2]
   double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
   double* fout;       // [B] eval hook output
+  double* sbuf;       // [B][14][13*Nmax] per-sample gradient rows parked between the cost and the gradient phase
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
   double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
