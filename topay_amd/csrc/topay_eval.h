@@ -403,6 +403,12 @@ struct GradGate {
   bool always;      // first evaluation of a run, test hooks
   bool has_early;   // past > 0
   double finit, thr /* finit + stp * dgtest */, early /* delta / past */;
+  // Early rejection (stage 2): every term of the cost is non-negative, so once the cost accumulated so far exceeds
+  // skip_thr the trial is certain to fail the sufficient-decrease test and certain not to be early-accepted; when the
+  // line search is also certain to continue after such a failure (early_ok, decided by the solver), nothing of this
+  // trial is read except that verdict, and the sample bodies of the remaining passes are skipped.
+  bool early_ok;
+  double skip_thr;
   __device__ __forceinline__ bool needs(double f) const {
     if (always) return true;
     if (isinf(f) || isnan(f)) return false;                                        // INVALID_FUNCVAL: reverted
@@ -1055,6 +1061,10 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   const int npass = (NE + 63) / 64;
   double cost_pen = 0.0;             // per-lane partial penalty cost
   double carryx = 0.0, carryy = 0.0; // XY prefix carried across passes (relative to start)
+  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
+  const double time_cost = wT * wave_sum(lane < N ? c_Tp[lane] : 0.0);
+  bool skip_body = false;            // early rejection (GradGate): the rest of the sample bodies is not needed
+  double f_skip = 0.0;
 
   const double wM = STAGE == 1 ? P.s1_moment_weight : P.s2_moment_weight;
   const double wA = STAGE == 1 ? P.s1_acc_weight : P.s2_acc_weight;
@@ -1098,7 +1108,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #ifdef TOPAY_STAMPS
 #endif
     SUBSTAMP_BEGIN(C);
-    if (act) {
+    if (act && !skip_body) {
       Basis B;
       make_basis(j * half, B);
       const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
@@ -1197,13 +1207,13 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       cost_pen += cst;
     }
     SUBSTAMP_END(C, 12);  // sample body of lane 0
-    if (act) {
+    if (act && !skip_body) {
       gxy[2 * e] = gpx;
       gxy[2 * e + 1] = gpy;
     }
     // ---- park the per-sample gradient rows in HBM ([value][sample], coalesced): whether they are needed is only known
     // once the cost of the whole trajectory is (GradGate)
-    if (act) {
+    if (act && !skip_body) {
       glb_dp sb = C.sbuf + e;
       const int ss = C.sb_stride;
 #pragma unroll
@@ -1213,6 +1223,13 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #pragma unroll
         for (int v = 0; v < 7; v++) sb[(6 + v) * ss] = gB[5 + v];
         sb[13 * ss] = jva ? 1.0 : 0.0;
+      }
+    }
+    if (STAGE == 2 && gate.early_ok && !skip_body && pass + 1 < npass) {
+      const double partial = jerk_cost + wave_sum(cost_pen) + time_cost;
+      if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
+        skip_body = true;
+        f_skip = partial;
       }
     }
   }
@@ -1267,12 +1284,11 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
   const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
   lds_sync();
-  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
-  const double time_cost = wT * wave_sum(lane < N ? c_Tp[lane] : 0.0);
   const double f_total = jerk_cost + (bad ? 1.0e+22 : penalty_cost) + time_cost;
 
   STAMP(C, 5);  // between sweeps
   // ---- the cost is known: is the gradient going to be read?  (wave-uniform)
+  if (skip_body) return f_skip;   // certain rejection: a lower bound of the cost that already fails the test
   if (!gate.needs(f_total)) return f_total;
 
   // =========================== gradient phase ===========================

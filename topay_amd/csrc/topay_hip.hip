@@ -90,6 +90,7 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
   for (int r = 0; r < repeats; r++) {
     GradGate gate;
     gate.always = true; gate.has_early = false; gate.finit = 0.0; gate.thr = 0.0; gate.early = 0.0;
+    gate.early_ok = false; gate.skip_thr = 0.0;
     if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
     else f = eval_cost_grad<2, RMAX>(C, mp, gate);
   }

@@ -102,6 +102,16 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     gate.finit = finit;
     gate.thr = finit + stp * dgtest;      // the line search's own expressions (below)
     gate.early = past > 0 ? lp.delta / past : 0.0;
+    // would the line search go on to another trial if this one failed the sufficient-decrease test?  (the checks that
+    // follow such a failure below: trial budget, bracket width, step bounds)
+    {
+      const double stp_next = 0.5 * (mu + stp);
+      gate.early_ok = mode == MODE_LS && (count + 1 < lp.max_linesearch) && !((stp - mu) < lp.machine_prec * stp) &&
+                      !(stp_next < lp.min_step) && !(stp_next > lp.max_step);
+      // twice the early-accept tolerance: the verdict must not hinge on how the solver rounds its own test
+      const double no_early = past > 0 ? finit + 2.0 * gate.early * (fabs(finit) + 1.0) : gate.thr;
+      gate.skip_thr = gate.thr > no_early ? gate.thr : no_early;
+    }
     if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
     else f = eval_cost_grad<2, RMAX>(C, mp, gate);
     evals++;
