@@ -1065,6 +1065,13 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   const double time_cost = wT * wave_sum(lane < N ? c_Tp[lane] : 0.0);
   bool skip_body = false;            // early rejection (GradGate): the rest of the sample bodies is not needed
   double f_skip = 0.0;
+  if (STAGE == 2 && gate.early_ok) {  // smoothness + time alone may already decide (a wild step)
+    const double partial = jerk_cost + time_cost;
+    if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
+      skip_body = true;
+      f_skip = partial;
+    }
+  }
 
   const double wM = STAGE == 1 ? P.s1_moment_weight : P.s2_moment_weight;
   const double wA = STAGE == 1 ? P.s1_acc_weight : P.s2_acc_weight;
