@@ -230,7 +230,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     out = {
-        "metric": "trajectories/sec to L-BFGS convergence (benchmark_tables batch)",
+        "metric": "trajectories/sec to L-BFGS convergence (benchmark_tables batch) at 1/2/4/8 GPU",
         "value": total_traj * args.steps / elapsed,
         "unit": "trajectories/s",
         "n_gpus": world,
