@@ -68,3 +68,35 @@ def test_no_device_means_loud_failure(hip_lib):
 def test_missing_library_is_an_error(tmp_path):
     with pytest.raises(api.TopayError):
         api.load(str(tmp_path / "libtopay_hip.so"))
+
+
+def _build_demo(out):
+    """examples/cabi_demo.cpp: a plain C++ caller of include/topay.h (no Python, no torch), linked against the library."""
+    import subprocess
+
+    lib_dir = os.path.join(ROOT, "topay_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "cabi_demo.cpp"), "-o", out,
+                           os.path.join(lib_dir, "libtopay_hip.so"), "-Wl,-rpath," + lib_dir])
+
+
+def test_cpp_caller_links_against_the_boundary(hip_lib, tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "cabi_demo")
+    _build_demo(exe)
+    # without a device the demo must stop at topay_create with the library's error text, not compute anything
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "topay_create" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_caller_runs_on_the_device(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "cabi_demo")
+    _build_demo(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("candidate")]
+    assert len(lines) == 2 and all("success 1" in ln for ln in lines)
