@@ -21,7 +21,7 @@ import sys
 import time
 
 # before anything initialises HIP (torch.cuda does): the solver's bucket streams need distinct hardware queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -63,18 +63,21 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scenarios", type=int, default=1024, help="scenarios per GPU (x 8 candidates each)")
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial", action="store_true", help="skip the strictly serial steps measured beside a pipelined run")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] latency figure (profiling runs)")
     ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
                     help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
                          "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
     ap.add_argument("--hires-size", type=float, default=50.0)
-    ap.add_argument("--inflight", type=int, default=1, help="batches (contexts) in flight per GPU; 1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches (contexts) in flight per GPU: step i+1 is issued while step i is still solving and its waves take the "
+                         "SIMDs step i's tail leaves idle; 1 = strictly serial steps (also measured and reported beside the line)")
     args = ap.parse_args()
 
     import torch
@@ -148,25 +151,42 @@ def main():
         o_.reset()                       # init kernel from the resident raw paths (optimizeTraj:146-357)
         o_.optimize_async()              # persistent solve kernel (optimizeTraj:359-497)
 
+    gathers = []
+    trace = os.environ.get("TOPAY_BENCH_TRACE") == "1"
+    tr0 = time.perf_counter()
+
     def finish(o_):
+        ta = time.perf_counter()
         ok = o_.finish()                 # waits for this context's stream
         ms, _ = o_.last_kernel_ms()
+        tb_ = time.perf_counter()
         if distributed:                  # the one exchange of the path: per-scenario result records over RCCL
             dur = o_.total_durations()   # the planner keeps the shortest successful candidate of a scenario
             recs = tdist.scenario_records(scen_ids, scen_global, ok.astype(np.int32), o_.traj_cost, n_pieces, dur)
-            tdist.gather_records(recs, max_rows=S, device=dev)
+            tc = time.perf_counter()
+            # the exchange of step i is started here and collected while step i+1's records are being prepared: the RCCL
+            # kernel has to find a compute unit on a device whose SIMDs all hold resident solver waves of the next batch
+            gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
+            while len(gathers) > 1:
+                tdist.gather_records_end(gathers.pop(0))
+            if trace:
+                print(f"[trace] finish at {1e3 * (ta - tr0):.0f} ms: wait {1e3 * (tb_ - ta):.1f}, records {1e3 * (tc - tb_):.1f}, "
+                      f"gather {1e3 * (time.perf_counter() - tc):.1f} ms", file=sys.stderr)
         return ok, ms
 
-    def run(nsteps):
-        """nsteps steps, at most `depth` in flight; every step is waited for and its records gathered."""
+    def run(nsteps, depth_=None):
+        """nsteps steps, at most `depth_` in flight; every step is waited for and its records gathered."""
+        depth_ = depth if depth_ is None else depth_
         out_ = []
         for i in range(nsteps):
-            o_ = opts[i % depth]
-            if i >= depth:
+            o_ = opts[i % depth_]
+            if i >= depth_:
                 out_.append(finish(o_))
             issue(o_)
-        for i in range(max(0, nsteps - depth), nsteps):
-            out_.append(finish(opts[i % depth]))
+        for i in range(max(0, nsteps - depth_), nsteps):
+            out_.append(finish(opts[i % depth_]))
+        while gathers:                   # every step's records are on every rank before the step counts as done
+            tdist.gather_records_end(gathers.pop(0))
         return out_
 
     run(args.warmup)
@@ -181,6 +201,16 @@ def main():
     elapsed = time.perf_counter() - t_start
     ok = res[-1][0]
     kernel_ms = [r[1] for r in res]
+    # the same steps strictly one after the other (outside the timed region): the per-launch figures of the roofline
+    # block and of the rocprofv3 kernel trace are only well defined when launches of different steps do not overlap
+    serial = None
+    if depth > 1 and not args.no_serial:
+        ns = max(1, min(3, args.steps))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        rs = run(ns, 1)
+        torch.cuda.synchronize()
+        serial = {"steps": ns, "ms_per_step": (time.perf_counter() - ts) / ns * 1e3, "kernel_ms": float(np.mean([r[1] for r in rs]))}
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -215,6 +245,10 @@ def main():
     # true per-launch cost).
     kms = float(np.mean(kernel_ms)) if depth == 1 else elapsed / args.steps * 1e3
     achieved = abytes / (kms * 1e-3) / 1e9
+    if serial is not None:
+        serial["trajectories_per_s_per_gpu"] = B / (serial["ms_per_step"] * 1e-3)
+        serial["achieved_GBps"] = abytes / (serial["kernel_ms"] * 1e-3) / 1e9
+        serial["frac"] = serial["achieved_GBps"] / HBM_PEAK_GBS
     # HBM-side bytes of one step from the committed PMC passes of this same command (tools/profile_round.sh; FETCH_SIZE
     # and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected live here).  Only quoted when the
     # workload is the one that was profiled.
@@ -264,8 +298,14 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3 (persistent per-trajectory solve, one concurrent launch per N-bucket)",
-            "kernel_ms": kms, "kernel_span_ms_each": [float(k) for k in kernel_ms], "steps_in_flight": depth,
+            "kernel": "k_solve1/2/3 (persistent solve: one workgroup per SIMD slot takes candidates from its class's queue; the "
+                      "three class launches of a batch run concurrently)",
+            "kernel_ms": kms,
+            "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else
+                                     "wall time of the timed region / steps (launches of consecutive steps overlap; the event span of each "
+                                     "is in kernel_span_ms_each, the non-overlapping figures in serial_steps)"),
+            "kernel_span_ms_each": [float(k) for k in kernel_ms], "steps_in_flight": depth,
+            "serial_steps": serial,
             "algorithmic_bytes_per_step": abytes,
         },
     }

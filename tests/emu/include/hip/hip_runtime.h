@@ -194,6 +194,7 @@ inline unsigned long long __ballot(int pred) {
   return bits;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }  // lanes are fibers of one thread
 inline int __all(int pred) {
   int lanes = (int)(hip_emu::S().bdim.x);
   unsigned long long full = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1);
@@ -265,6 +266,13 @@ inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
 #define hipStreamNonBlocking 1
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
+inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
+struct hipDeviceProp_t { int multiProcessorCount = 2; };   // two 'CUs': the persistent launches of the tests really loop
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu(); return 0; }

@@ -1,0 +1,60 @@
+"""Timeline of a pipelined sequence of batches (bench.py's issue/finish order) on the device's constant clock."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from topay_amd import api
+from topay_amd.harness import workload as wl
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+tb = wl.TablesBatch(S, 8, base_seed=42, nthreads=0)
+worlds = [tb.world(s) for s in tb.scenarios]
+slot = {s: k for k, s in enumerate(tb.scenarios)}
+map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+opts = []
+for _ in range(depth):
+    o = api.MomaTrajOptBatch(device=0)
+    w0 = worlds[0]
+    o.build_esdf_batch(w0.origin, w0.res, w0.dims, w0.min_b, w0.max_b, np.stack([w.occ2d for w in worlds]),
+                       np.stack([w.occ3d for w in worlds]))
+    o.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+    opts.append(o)
+for o in opts:
+    o.reset(); o.optimize()
+N = opts[0].n_pieces(); m = N > 0
+rec = []
+t0 = time.perf_counter()
+def fin(i):
+    o = opts[i % depth]; o.finish()
+    rec.append((i, o.start_us()[m].copy(), o.elapsed_us()[m].copy(), time.perf_counter() - t0))
+host = []
+for i in range(steps):
+    o = opts[i % depth]
+    if i >= depth: fin(i - depth)
+    a = time.perf_counter() - t0
+    o.reset(); o.optimize_async()
+    host.append((i, a, time.perf_counter() - t0))
+for i in range(max(0, steps - depth), steps): fin(i)
+total = time.perf_counter() - t0
+print(f"{steps} steps depth {depth}: {total*1e3:.0f} ms -> {steps*m.sum()/total:.0f} traj/s")
+base = min(r[1].min() for r in rec)
+for (i, a, b) in host: print(f"  host: issue {i} called at {a*1e3:.0f} ms returned at {b*1e3:.0f} ms")
+for (i, s, u, th) in rec:
+    s = s - base
+    print(f"  batch {i}: first start {s.min()/1e3:.0f}, median start {np.median(s)/1e3:.0f}, last start {s.max()/1e3:.0f}, last end {(s+u).max()/1e3:.0f} (host saw finish at {th*1e3:.0f})")
+T = max((r[1] - base + r[2]).max() for r in rec)
+nb = 40
+edges = np.linspace(0, T, nb + 1)
+tot = np.zeros(nb)
+for (i, s, u, th) in rec:
+    s = s - base; e = s + u
+    tot += np.array([np.clip(np.minimum(e, edges[k + 1]) - np.maximum(s, edges[k]), 0, None).sum() / (edges[k + 1] - edges[k]) for k in range(nb)])
+ends = np.array([ (r[1] - base + r[2]).max() for r in rec ]); fs = np.array([(r[1] - base).min() for r in rec])
+print("  batch latency ms (first start to last end):", [int(round(v / 1e3)) for v in ends - fs], " cadence ms:", [int(round(v / 1e3)) for v in np.diff(ends)])
+fine = np.linspace(0, T, 401); totf = np.zeros(400)
+for (i, s, u, th) in rec:
+    s = s - base; e = s + u
+    si = np.searchsorted(fine, s); ei = np.searchsorted(fine, e)
+    d = np.zeros(402); np.add.at(d, si, 1); np.add.at(d, ei, -1); totf += np.cumsum(d)[1:401]
+print("  max resident (fine bins):", int(totf.max()))
+print(f"  total resident waves per {T/nb/1e3:.0f} ms bin:", [int(round(v)) for v in tot])

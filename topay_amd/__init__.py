@@ -7,4 +7,4 @@ variable once, at its first call, so this has to happen before anything initiali
 """
 import os
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

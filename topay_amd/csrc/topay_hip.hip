@@ -8,7 +8,10 @@
 #include <cstring>
 #include <numeric>
 #include <cstdlib>
+#include <chrono>
+#include <cmath>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -102,10 +105,17 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
 }
 
 template <int RMAX>
-__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds,
-                                           int init_stride_N) {
-  const int b = Bt.order[blockIdx.x];
+__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N, int b) {
   const unsigned long long t_begin = wall_clock64();
+  // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
+  // is resident, see topay_optimize_async
+  if (threadIdx.x == 0 && Bt.started) {
+#ifndef TOPAY_CPU_EMU
+    __hip_atomic_fetch_add(Bt.started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    Bt.started[0] += 1;
+#endif
+  }
   EvalCtx C;
   load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
@@ -158,6 +168,28 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 #else
     Bt.hw_id[b] = 0;
 #endif
+  }
+}
+
+// Persistent launch: the grid is one workgroup per SIMD slot (or fewer), and every workgroup takes candidates from the
+// launch's queue -- positions of `order`, longest first -- until it is empty.  The hardware dispatcher places workgroups
+// in order on a fixed round-robin of XCDs / shader engines and stalls on a full one while others have room (about 10 %
+// of the slots stay empty when it has to place 8000 workgroups of unequal length); a resident wave that fetches its
+// next candidate itself leaves no slot idle and starts candidates strictly in queue order.  Which wave solves which
+// candidate is timing-dependent, the result of a candidate is not (nothing is shared between candidates).
+template <int RMAX>
+__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N) {
+  if (!Bt.queue_next) {
+    solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
+    return;
+  }
+  for (;;) {
+    int pos = 0;
+    if (threadIdx.x == 0) pos = atomicAdd(Bt.queue_next, 1);
+    pos = __shfl(pos, 0);
+    if (pos >= Bt.queue_count) break;
+    solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[pos]);
+    __syncthreads();
   }
 }
 
@@ -295,16 +327,17 @@ static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32};
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
 // GPU_MAX_HW_QUEUES=8 itself.
-__attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-#define TOPAY_MAX_DEVICES 16
-static hipStream_t g_bucket_streams[TOPAY_MAX_DEVICES][TOPAY_NBUCKET] = {};
-static std::mutex g_bucket_mutex;
+__attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Dispatch gate (topay_optimize_async): the context whose solve was issued last in this process.
+struct topay_ctx;
+static std::mutex g_issue_mutex;
+static topay_ctx* g_last_issued = nullptr;
 
 struct topay_ctx {
   int device = 0;
   topay_params_t hp;
   DevParams dp;
-  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // maps
   std::vector<DevMap> hmaps = std::vector<DevMap>(TOPAY_MAX_MAPS);
@@ -321,6 +354,12 @@ struct topay_ctx {
   hipEvent_t bevent[NBUCKET] = {nullptr};
   hipEvent_t bstart = nullptr;
   bool pending = false;  // a topay_optimize_async has been issued and not yet waited for
+  int* h_started = nullptr;  // pinned host counter the solve kernels bump once per candidate (dispatch gate)
+  int n_launched = 0;        // candidates the pending solve launched
+  bool gate = true;
+  bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
+  int simd_slots = 1024;
+  DevBuf qnext;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
@@ -401,6 +440,14 @@ static int sphere_layout_ok(const topay_params_t& p) {
   return 1;
 }
 
+// Every copy goes through the context's own (non-blocking) stream: null-stream operations would wait for the solves of
+// every other context of the process (and they for it), which serialises batches that are meant to overlap.
+static hipError_t memcpy_sync(topay_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, n, kind, c->stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(c->stream);
+}
+
 extern "C" {
 
 const char* topay_last_error(void) { return g_err.c_str(); }
@@ -475,24 +522,36 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   c->device = device;
   c->hp = *params;
   make_dev_params(*params, c->dp);
-  HIPCHK(hipStreamCreate(&c->stream));
-  HIPCHK(hipStreamCreate(&c->stream2));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
   HIPCHK(hipEventCreate(&c->bstart));
-  // The bucket streams are shared by every context of the process on this device: a second batch issued while the
-  // first is still running queues each of its buckets behind the same bucket of the first, so its short-trajectory
-  // buckets start as soon as the first batch's have drained and fill the SIMDs the first batch's tail leaves idle.
-  const int dev_slot = device % TOPAY_MAX_DEVICES;
-  {
-    std::lock_guard<std::mutex> lk(g_bucket_mutex);
-    for (int k = 0; k < topay_ctx::NBUCKET; k++)
-      if (!g_bucket_streams[dev_slot][k])
-        HIPCHK(hipStreamCreateWithFlags(&g_bucket_streams[dev_slot][k], hipStreamNonBlocking));
-  }
+  // Three streams per context (the last class runs on the main stream), all non-blocking and never the null stream:
+  // two contexts then use six of the eight hardware queues the library asks for, and no operation of one context
+  // waits for another context's solve.
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    c->bstream[k] = g_bucket_streams[dev_slot][k];
+    if (k == topay_ctx::NBUCKET - 1) c->bstream[k] = c->stream;
+    else HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->bevent[k]));
+  }
+  {
+    const char* pe = getenv("TOPAY_PERSISTENT");
+    c->persistent = !(pe && pe[0] == '0');
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->simd_slots = 4 * prop.multiProcessorCount;   // one wave per SIMD (TOPAY_WAVES_PER_EU = 1), four SIMDs per CU
+    // a few slots stay free for the small kernels other libraries launch while a solve is resident (torch fills and
+    // copies, the RCCL gather of the result records): with every slot taken they would wait for a workgroup to exit
+    const char* rs = getenv("TOPAY_RESERVE_SLOTS");
+    c->simd_slots = std::max(64, c->simd_slots - (rs ? atoi(rs) : 0));
+  }
+  {
+    const char* g = getenv("TOPAY_DISPATCH_GATE");
+    c->gate = !(g && g[0] == '0');
+    void* hp = nullptr;
+    HIPCHK(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    c->h_started = (int*)hp;
+    c->h_started[0] = 0;
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
@@ -507,17 +566,22 @@ void topay_destroy(topay_ctx* c) {
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
-                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io};
+                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     if (c->bevent[k]) (void)hipEventDestroy(c->bevent[k]);
+    if (c->bstream[k] && c->bstream[k] != c->stream) (void)hipStreamDestroy(c->bstream[k]);
   }
+  {
+    std::lock_guard<std::mutex> lk(g_issue_mutex);
+    if (g_last_issued == c) g_last_issued = nullptr;
+  }
+  if (c->h_started) (void)hipHostFree(c->h_started);
   if (c->bstart) (void)hipEventDestroy(c->bstart);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -529,8 +593,8 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   topay_status s;
   if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
   if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
-  HIPCHK(hipMemcpy(c->map2d[map_id].p, esdf2d, n2 * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->map3d[map_id].p, esdf3d, n3 * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->map2d[map_id].p, esdf2d, n2 * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->map3d[map_id].p, esdf3d, n3 * 8, hipMemcpyHostToDevice));
   DevMap& m = c->hmaps[map_id];
   for (int i = 0; i < 3; i++) {
     m.origin[i] = desc->origin[i]; m.dims[i] = desc->dims[i];
@@ -541,7 +605,7 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
   m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
   c->have_map[map_id] = 1;
-  HIPCHK(hipMemcpy((char*)c->dmaps.p + sizeof(DevMap) * map_id, &c->hmaps[map_id], sizeof(DevMap), hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, (char*)c->dmaps.p + sizeof(DevMap) * map_id, &c->hmaps[map_id], sizeof(DevMap), hipMemcpyHostToDevice));
   return TOPAY_OK;
 }
 
@@ -681,8 +745,8 @@ topay_status topay_get_map(topay_ctx* c, int map_id, double* esdf2d, double* esd
   HIPCHK(hipSetDevice(c->device));
   const DevMap& m = c->hmaps[map_id];
   const size_t n2 = (size_t)m.dims[0] * m.dims[1], n3 = n2 * m.dims[2];
-  if (esdf2d) HIPCHK(hipMemcpy(esdf2d, c->map2d[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
-  if (esdf3d) HIPCHK(hipMemcpy(esdf3d, c->map3d[map_id].p, n3 * 8, hipMemcpyDeviceToHost));
+  if (esdf2d) HIPCHK(memcpy_sync(c, esdf2d, c->map2d[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf3d) HIPCHK(memcpy_sync(c, esdf3d, c->map3d[map_id].p, n3 * 8, hipMemcpyDeviceToHost));
   if (build_ms) *build_ms = c->last_edt_ms;
   return TOPAY_OK;
 }
@@ -726,14 +790,14 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(init_xy, (size_t)batch * 2 * TOPAY_MAX_N * 8);
   ENS(x0, (size_t)batch * (10 * TOPAY_MAX_N - 8) * 8);
   ENS(order, (size_t)batch * 4);
-  HIPCHK(hipMemcpy(c->paths.p, init_paths, tot * 10 * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->path_off.p, off.data(), (size_t)(batch + 1) * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->path_len.p, path_len, (size_t)batch * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->map_id.p, mids.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
-  if (boundary_vel) HIPCHK(hipMemcpy(c->bvel.p, boundary_vel, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
-  else HIPCHK(hipMemset(c->bvel.p, 0, (size_t)batch * 20 * 8));
-  if (boundary_acc) HIPCHK(hipMemcpy(c->bacc.p, boundary_acc, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
-  else HIPCHK(hipMemset(c->bacc.p, 0, (size_t)batch * 20 * 8));
+  HIPCHK(memcpy_sync(c, c->paths.p, init_paths, tot * 10 * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->path_off.p, off.data(), (size_t)(batch + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->path_len.p, path_len, (size_t)batch * 4, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->map_id.p, mids.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+  if (boundary_vel) HIPCHK(memcpy_sync(c, c->bvel.p, boundary_vel, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemsetAsync(c->bvel.p, 0, (size_t)batch * 20 * 8, c->stream));
+  if (boundary_acc) HIPCHK(memcpy_sync(c, c->bacc.p, boundary_acc, (size_t)batch * 20 * 8, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemsetAsync(c->bacc.p, 0, (size_t)batch * 20 * 8, c->stream));
   DevBatch& d = c->db;
   memset(&d, 0, sizeof(d));
   d.B = batch;
@@ -745,7 +809,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   if ((s = run_init(c)) != TOPAY_OK) return s;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->hN.assign(batch, 0);
-  HIPCHK(hipMemcpy(c->hN.data(), c->N.p, (size_t)batch * 4, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, c->hN.data(), c->N.p, (size_t)batch * 4, hipMemcpyDeviceToHost));
   int Nmax = 0;
   for (int b = 0; b < batch; b++) {
     if (c->hN[b] <= 0) c->hN[b] = 0;  // needs more than TOPAY_MAX_N pieces: reported as failed, never launched
@@ -771,7 +835,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
     std::vector<int> ord;
     for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) ord.insert(ord.end(), c->cls[k].begin(), c->cls[k].end());
     ord.resize(batch, 0);
-    HIPCHK(hipMemcpy(c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
+    HIPCHK(memcpy_sync(c, c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
   }
   ENS(x, (size_t)batch * c->nmax * 8);
   ENS(work, (size_t)batch * 4 * c->nmax * 8);
@@ -806,9 +870,9 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.elapsed_us = c->elapsed.as<double>();
   d.start_us = c->startus.as<double>();
   d.hw_id = c->hwid.as<int>();
-  HIPCHK(hipMemset(c->elapsed.p, 0, (size_t)batch * 8));
-  HIPCHK(hipMemset(c->success.p, 0, (size_t)batch * 4));
-  HIPCHK(hipMemset(c->stats.p, 0, (size_t)batch * 32));
+  HIPCHK(hipMemsetAsync(c->elapsed.p, 0, (size_t)batch * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)batch * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->stats.p, 0, (size_t)batch * 32, c->stream));
   c->have_traj = true;
   return TOPAY_OK;
 }
@@ -823,13 +887,40 @@ topay_status topay_reset(topay_ctx* c) {
 }  // extern "C"
 
 template <typename KF1, typename KF2, typename KF3, typename... Args>
-static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args... args) {
+static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2, KF3 k3, Args... args) {
   // One launch per N-bucket, each on its own stream so that the tail of one bucket overlaps the others.
   // Longest jobs first.  The context's main stream waits for all of them (events), so the caller's
   // ev0/ev1 pair on the main stream brackets the whole solve.
   int launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
+  int slots = 0;
+  if (persistent) {
+    if (c->qnext.ensure(sizeof(int) * topay_ctx::NBUCKET) != TOPAY_OK) return TOPAY_ERR_NO_DEVICE;
+    HIPCHK(hipMemsetAsync(c->qnext.p, 0, sizeof(int) * topay_ctx::NBUCKET, c->stream));
+    slots = c->simd_slots;
+  }
+  // Persistent grids: the slots are divided between the classes in proportion to an estimate of their work
+  // (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly), so that the launches of
+  // one batch together ask for exactly the slots the device has and none of their workgroups waits in the dispatcher.
+  int share[topay_ctx::NBUCKET] = {0};
+  if (persistent) {
+    double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
+    for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+      for (int b : c->cls[k]) wk[k] += std::pow((double)c->hN[b], 1.5);
+      wt += wk[k];
+    }
+    int used = 0;
+    for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+      const int nk = (int)c->cls[k].size();
+      share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
+      used += share[k];
+    }
+    for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
+      const int kk = k % topay_ctx::NBUCKET;
+      if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
+    }
+  }
   HIPCHK(hipEventRecord(c->bstart, c->stream));  // params + resets on the main stream come first
   for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
     const std::vector<int>& v = c->cls[k];
@@ -840,25 +931,31 @@ static topay_status launch_classes(topay_ctx* c, KF1 k1, KF2 k2, KF3 k3, Args...
     DevBatch d = c->db;
     d.order = c->db.order + off;
     off += nk;
+    int grid = nk;
+    if (persistent) {
+      d.queue_next = c->qnext.as<int>() + k;
+      d.queue_count = nk;
+      grid = share[k];
+    }
     const size_t lds = solve_lds_bytes(nm);
     hipStream_t st = c->bstream[k];
-    HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
+    if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
     if (nm > 21) {
       HIPCHK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k3, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+      hipLaunchKernelGGL(k3, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     } else if (nm > 10) {
       HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k2, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+      hipLaunchKernelGGL(k2, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     } else {
       HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k1, dim3(nk), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+      hipLaunchKernelGGL(k1, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->bevent[k], st));
+    if (st != c->stream) HIPCHK(hipEventRecord(c->bevent[k], st));
     launches++;
   }
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
-    if (!c->cls[k].empty()) HIPCHK(hipStreamWaitEvent(c->stream, c->bevent[k], 0));
+    if (!c->cls[k].empty() && c->bstream[k] != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->bevent[k], 0));
   c->last_launches = launches;
   return TOPAY_OK;
 }
@@ -868,11 +965,41 @@ extern "C" {
 topay_status topay_optimize_async(topay_ctx* c) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) {  // a second solve on a context whose first has not been waited for: finish that one first
+    topay_status s0 = topay_synchronize(c);
+    if (s0 != TOPAY_OK) return s0;
+  }
+  {
+    // Dispatch gate.  Batches of different contexts run on different streams; issued at the same time their waves
+    // would be dispatched alternately and both would end in the same long tail.  Holding the new batch back until
+    // every candidate of the previous one is resident gives oldest-first scheduling without stream priorities: the
+    // new waves take exactly the SIMDs the previous batch's tail leaves idle.  Host-side wait on a counter in pinned
+    // memory (<= one bulk phase); results do not depend on it.
+    std::lock_guard<std::mutex> lk(g_issue_mutex);
+    topay_ctx* p = g_last_issued;
+    if (c->gate && p && p != c && p->pending && p->device == c->device && p->h_started) {
+      volatile int* cnt = p->h_started;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (*cnt < p->n_launched) {
+        if (hipStreamQuery(p->stream) == hipSuccess) break;  // finished (or never launched anything)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+      }
+    }
+    c->h_started[0] = 0;
+    int nl = 0;
+    for (auto& v : c->cls) nl += (int)v.size();
+    c->n_launched = nl;
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
+    c->db.started = (int*)dp;
+    g_last_issued = c;
+  }
   HIPCHK(hipEventRecord(c->ev0, c->stream));
   // candidates that were not launched keep success = 0 and cost = NaN
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
-  topay_status s = launch_classes(c, k_solve1, k_solve2, k_solve3);
+  topay_status s = launch_classes(c, c->persistent, k_solve1, k_solve2, k_solve3);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   c->pending = true;
@@ -909,8 +1036,8 @@ topay_status topay_get_nmax(topay_ctx* c, int* nmax, int* Nmax) {
 topay_status topay_get_batch(topay_ctx* c, int* success, double* cost, int* n_pieces) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
-  if (success) HIPCHK(hipMemcpy(success, c->success.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
-  if (cost) HIPCHK(hipMemcpy(cost, c->cost.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (success) HIPCHK(memcpy_sync(c, success, c->success.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(memcpy_sync(c, cost, c->cost.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   if (n_pieces) memcpy(n_pieces, c->hN.data(), (size_t)c->B * 4);
   return TOPAY_OK;
 }
@@ -918,9 +1045,9 @@ topay_status topay_get_batch(topay_ctx* c, int* success, double* cost, int* n_pi
 topay_status topay_get_elapsed_us(topay_ctx* c, double* us, double* start_us, int* hw_id) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
-  if (us) HIPCHK(hipMemcpy(us, c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
-  if (start_us) HIPCHK(hipMemcpy(start_us, c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
-  if (hw_id) HIPCHK(hipMemcpy(hw_id, c->hwid.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
+  if (us) HIPCHK(memcpy_sync(c, us, c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (start_us) HIPCHK(memcpy_sync(c, start_us, c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (hw_id) HIPCHK(memcpy_sync(c, hw_id, c->hwid.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -932,7 +1059,7 @@ topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* time
   if (i < 0 || i >= c->B || n_times < 0 || (n_times > 0 && (!times || !states))) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   std::vector<double> hT((size_t)c->Nmax);
-  HIPCHK(hipMemcpy(hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
   double t = 0.0;
   for (int k = 0; k < c->hN[i]; k++) t += hT[k];
   if (!(t > 0.0 && t < 1.0e4)) t = 0.0;
@@ -953,10 +1080,10 @@ topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* time
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   int ns = 0;
-  HIPCHK(hipMemcpy(&ns, d_nseq, 4, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, &ns, d_nseq, 4, hipMemcpyDeviceToHost));
   if (n_seq) *n_seq = ns;
-  if (seq && ns > 0) HIPCHK(hipMemcpy(seq, d_seq, (size_t)std::min(ns, seq_cap) * 4 * 8, hipMemcpyDeviceToHost));
-  if (n_times) HIPCHK(hipMemcpy(states, d_states, (size_t)n_times * 10 * 8, hipMemcpyDeviceToHost));
+  if (seq && ns > 0) HIPCHK(memcpy_sync(c, seq, d_seq, (size_t)std::min(ns, seq_cap) * 4 * 8, hipMemcpyDeviceToHost));
+  if (n_times) HIPCHK(memcpy_sync(c, states, d_states, (size_t)n_times * 10 * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -986,7 +1113,7 @@ topay_status topay_get_total_durations(topay_ctx* c, double* total) {
   if (!c || !c->have_traj || !total) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   std::vector<double> hT((size_t)c->B * c->Nmax);
-  HIPCHK(hipMemcpy(hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < c->B; b++) {
     double t = 0.0;
     for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)b * c->Nmax + i];  // PolyTrajectory::getTotalDuration, minco.hpp:304-313
@@ -998,14 +1125,14 @@ topay_status topay_get_total_durations(topay_ctx* c, double* total) {
 topay_status topay_get_alm(topay_ctx* c, double* alm) {
   if (!c || !c->have_traj || !alm) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpy(alm, c->alm.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, alm, c->alm.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
 topay_status topay_get_stats(topay_ctx* c, int* stats) {
   if (!c || !c->have_traj || !stats) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpy(stats, c->stats.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, stats, c->stats.p, (size_t)c->B * 32, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1021,20 +1148,20 @@ topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, i
     if (n_pieces) *n_pieces = 0;
     return TOPAY_OK;
   }
-  if (success) HIPCHK(hipMemcpy(success, c->success.as<int>() + i, 4, hipMemcpyDeviceToHost));
-  if (cost) HIPCHK(hipMemcpy(cost, c->cost.as<double>() + i, 8, hipMemcpyDeviceToHost));
+  if (success) HIPCHK(memcpy_sync(c, success, c->success.as<int>() + i, 4, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(memcpy_sync(c, cost, c->cost.as<double>() + i, 8, hipMemcpyDeviceToHost));
   if (n_pieces) *n_pieces = N;
-  if (durations) HIPCHK(hipMemcpy(durations, c->T.as<double>() + (size_t)i * c->Nmax, (size_t)N * 8, hipMemcpyDeviceToHost));
+  if (durations) HIPCHK(memcpy_sync(c, durations, c->T.as<double>() + (size_t)i * c->Nmax, (size_t)N * 8, hipMemcpyDeviceToHost));
   if (coeffs) {
     std::vector<double> cm((size_t)9 * rows);
-    HIPCHK(hipMemcpy(cm.data(), c->coef.as<double>() + (size_t)i * 9 * 6 * c->Nmax, cm.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(c, cm.data(), c->coef.as<double>() + (size_t)i * 9 * 6 * c->Nmax, cm.size() * 8, hipMemcpyDeviceToHost));
     // getTraj(): per piece the 6x9 block transposed, highest order first — minco.hpp:908-921
     for (int p = 0; p < N; p++)
       for (int d = 0; d < 9; d++)
         for (int k = 0; k < 6; k++) coeffs[((size_t)p * 9 + d) * 6 + k] = cm[(size_t)d * rows + 6 * p + 5 - k];
   }
   if (knots_xy)
-    HIPCHK(hipMemcpy(knots_xy, c->knots.as<double>() + (size_t)i * 2 * (c->Nmax + 1), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(c, knots_xy, c->knots.as<double>() + (size_t)i * 2 * (c->Nmax + 1), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1047,8 +1174,8 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
   if (n) *n = nn;
   if (x) {
     // after optimize: the final iterate; before: the packed initial guess
-    if (c->solved) HIPCHK(hipMemcpy(x, c->x.as<double>() + (size_t)i * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
-    else HIPCHK(hipMemcpy(x, c->x0.as<double>() + (size_t)i * (10 * TOPAY_MAX_N - 8), (size_t)nn * 8, hipMemcpyDeviceToHost));
+    if (c->solved) HIPCHK(memcpy_sync(c, x, c->x.as<double>() + (size_t)i * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+    else HIPCHK(memcpy_sync(c, x, c->x0.as<double>() + (size_t)i * (10 * TOPAY_MAX_N - 8), (size_t)nn * 8, hipMemcpyDeviceToHost));
   }
   return TOPAY_OK;
 }
@@ -1060,15 +1187,15 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   HIPCHK(hipSetDevice(c->device));
   const int N = c->hN[i], nn = 10 * N - 8;
   if (N == 0) return TOPAY_ERR_TOO_MANY_PIECES;
-  HIPCHK(hipMemcpy(c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
   double alm[4] = {alm_lambda ? alm_lambda[0] : c->hp.alm_init_lambda[0], alm_lambda ? alm_lambda[1] : c->hp.alm_init_lambda[1],
                    alm_rho ? alm_rho[0] : c->hp.alm_init_rho[0], alm_rho ? alm_rho[1] : c->hp.alm_init_rho[1]};
-  HIPCHK(hipMemcpy(c->alm.as<double>() + (size_t)i * 4, alm, 32, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->alm.as<double>() + (size_t)i * 4, alm, 32, hipMemcpyHostToDevice));
   // single-block launch through a one-entry order array placed at the end of the order buffer
   DevBuf tmp;
   topay_status s = tmp.ensure(4);
   if (s != TOPAY_OK) return s;
-  HIPCHK(hipMemcpy(tmp.p, &i, 4, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, tmp.p, &i, 4, hipMemcpyHostToDevice));
   DevBatch d = c->db;
   d.order = tmp.as<int>();
   const size_t lds = solve_lds_bytes(N);
@@ -1086,9 +1213,9 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   tmp.release();
-  if (f) HIPCHK(hipMemcpy(f, c->fout.as<double>() + i, 8, hipMemcpyDeviceToHost));
-  if (g) HIPCHK(hipMemcpy(g, c->work.as<double>() + (size_t)i * 4 * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
-  if (final_xy_error) HIPCHK(hipMemcpy(final_xy_error, c->xyerr.as<double>() + 2 * i, 16, hipMemcpyDeviceToHost));
+  if (f) HIPCHK(memcpy_sync(c, f, c->fout.as<double>() + i, 8, hipMemcpyDeviceToHost));
+  if (g) HIPCHK(memcpy_sync(c, g, c->work.as<double>() + (size_t)i * 4 * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+  if (final_xy_error) HIPCHK(memcpy_sync(c, final_xy_error, c->xyerr.as<double>() + 2 * i, 16, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1099,7 +1226,7 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   HIPCHK(hipSetDevice(c->device));
   // x <- x0 (strided copy), alm <- init
   std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);
-  HIPCHK(hipMemcpy(x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < c->B; b++) {
     if (c->hN[b] == 0) continue;
     const int nn = 10 * c->hN[b] - 8;
@@ -1107,17 +1234,17 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
     alm[4 * b] = c->hp.alm_init_lambda[0]; alm[4 * b + 1] = c->hp.alm_init_lambda[1];
     alm[4 * b + 2] = c->hp.alm_init_rho[0]; alm[4 * b + 3] = c->hp.alm_init_rho[1];
   }
-  HIPCHK(hipMemcpy(c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  topay_status s = launch_classes(c, k_eval1, k_eval2, k_eval3, stage, repeats);
+  topay_status s = launch_classes(c, false, k_eval1, k_eval2, k_eval3, stage, repeats);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_ms = ms;
-  if (f) HIPCHK(hipMemcpy(f, c->fout.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+  if (f) HIPCHK(memcpy_sync(c, f, c->fout.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1131,7 +1258,7 @@ topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, 
   const int B = c->B;
   // scratch is sized from the longest returned trajectory
   std::vector<double> hT((size_t)B * c->Nmax);
-  HIPCHK(hipMemcpy(hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
   double tmax = 0.0;
   for (int b = 0; b < B; b++) {
     double t = 0.0;
@@ -1151,12 +1278,12 @@ topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, 
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   std::vector<int> fl((size_t)B * 2);
-  HIPCHK(hipMemcpy(fl.data(), c->feas_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, fl.data(), c->feas_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
   for (int b = 0; b < B; b++) {
     if (feasible) feasible[b] = fl[2 * b];
     if (strict) strict[b] = fl[2 * b + 1];
   }
-  if (report) HIPCHK(hipMemcpy(report, c->feas_report.p, (size_t)B * 38 * 8, hipMemcpyDeviceToHost));
+  if (report) HIPCHK(memcpy_sync(c, report, c->feas_report.p, (size_t)B * 38 * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1170,7 +1297,7 @@ topay_status topay_set_trace(topay_ctx* c, int cap) {
   if (cap > 0) {
     topay_status s = c->trace.ensure((size_t)c->B * cap * 8);
     if (s != TOPAY_OK) return s;
-    HIPCHK(hipMemset(c->trace.p, 0, (size_t)c->B * cap * 8));
+    HIPCHK(hipMemsetAsync(c->trace.p, 0, (size_t)c->B * cap * 8, c->stream));
     c->db.trace = c->trace.as<double>();
     c->db.trace_cap = cap;
   }
@@ -1179,7 +1306,7 @@ topay_status topay_set_trace(topay_ctx* c, int cap) {
 topay_status topay_get_trace(topay_ctx* c, int i, double* out) {
   if (!c || !c->have_traj || c->trace_cap <= 0 || i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpy(out, c->trace.as<double>() + (size_t)i * c->trace_cap, (size_t)c->trace_cap * 8, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, out, c->trace.as<double>() + (size_t)i * c->trace_cap, (size_t)c->trace_cap * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1192,12 +1319,12 @@ topay_status topay_test_math(topay_ctx* c, int n, const double* a, const double*
   if ((s = da.ensure((size_t)n * 8)) != TOPAY_OK || (s = dbb.ensure((size_t)n * 8)) != TOPAY_OK ||
       (s = dout.ensure((size_t)n * 32)) != TOPAY_OK)
     return s;
-  HIPCHK(hipMemcpy(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dbb.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, da.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, dbb.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_math, dim3((n + 63) / 64), dim3(64), 0, c->stream, da.as<double>(), dbb.as<double>(), dout.as<double>(), n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  HIPCHK(memcpy_sync(c, out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   da.release(); dbb.release(); dout.release();
   return TOPAY_OK;
 }

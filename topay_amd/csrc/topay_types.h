@@ -105,6 +105,9 @@ struct DevBatch {
   double* fout;       // [B] eval hook output
   double* sbuf;       // [B][14][13*Nmax] per-sample gradient rows parked between the cost and the gradient phase
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
+  int* queue_next;    // persistent launches: next position of `order` to hand out (device counter); null = one workgroup per position
+  int queue_count;    // positions of `order` this launch owns
+  int* started;       // one counter in pinned host memory: candidates of this launch that have begun (dispatch gate; may be null)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
   double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
   const int* order;   // [B] block -> trajectory map

@@ -54,9 +54,11 @@ def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durati
     return recs
 
 
-def gather_records(local_records, max_rows, device=None):
-    """All-gather of the per-scenario records (padded to max_rows rows per rank).  Returns the concatenated
-    valid rows on every rank.  Uses the default process group (nccl/RCCL on GPUs, gloo in CPU tests)."""
+def gather_records_begin(local_records, max_rows, device=None):
+    """Starts the all-gather of the per-scenario records (padded to max_rows rows per rank) and returns a handle for
+    gather_records_end.  Nothing here waits for the collective: with a persistent solve of the next batch resident on
+    every SIMD, the RCCL kernel only gets a compute unit when workgroups of that solve exit, so the caller collects the
+    result one step later.  Uses the default process group (nccl/RCCL on GPUs, gloo in CPU tests)."""
     import torch
     import torch.distributed as dist
 
@@ -69,7 +71,19 @@ def gather_records(local_records, max_rows, device=None):
     if device is not None:
         buf = buf.to(device)
     out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    rows = torch.cat(out).cpu().numpy()
+    work = dist.all_gather(out, buf, async_op=True)
+    return work, out, buf
+
+
+def gather_records_end(handle):
+    """Waits for a gather started by gather_records_begin; returns the concatenated valid rows (on every rank)."""
+    work, out, _ = handle
+    work.wait()
+    rows = np.concatenate([o.cpu().numpy() for o in out])   # per-rank copies: no concatenation kernel on a busy device
     valid = rows[:, RECORD_WIDTH] == 1.0
     return rows[valid, :RECORD_WIDTH]
+
+
+def gather_records(local_records, max_rows, device=None):
+    """All-gather of the per-scenario records, synchronous form."""
+    return gather_records_end(gather_records_begin(local_records, max_rows, device))
