@@ -6,15 +6,17 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1"   # strictly serial steps: clean per-step spans
+ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1"   # strictly serial steps: launches of different steps do not overlap, per-launch figures are well defined
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/bench_kt.json 2> $OUT/kt.log
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log
 [ -x $ROOT/tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/tools/pmc_calib $ROOT/tools/pmc_calib.hip 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- $ROOT/tools/pmc_calib > $OUT/calib.txt 2> $OUT/cal_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- $ROOT/tools/pmc_calib >> $OUT/calib.txt 2> $OUT/cal_write.log
+# the default (pipelined, two batches in flight) command under the kernel trace, then plain
+rocprofv3 --kernel-trace --stats -d $OUT/kt2 -o kt -- python3 $ROOT/bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial > $OUT/bench_kt2.json 2> $OUT/kt2.log
 python3 $ROOT/bench.py $ARGS > $OUT/bench_plain.json 2>/dev/null
-python3 $ROOT/bench.py --gpus 1 --steps 3 --warmup 1 > $OUT/bench_default.json 2>/dev/null
+python3 $ROOT/bench.py > $OUT/bench_default.json 2>/dev/null
 find $OUT -name "*.csv" | head -50
 # keep the merge-back small: kernel trace CSVs of the bench can be large
 find $OUT -name "*.csv" -size +20M -exec gzip {} \;

@@ -32,9 +32,9 @@ def main(src, dst, tag):
                        "accum_vgpr_count, sgpr_count from kernels where name like 'k_solve%' order by start")
     t0 = rows[0][2]
     out.append("")
-    out.append("## Solve-kernel dispatches (one per N-bucket, concurrent on three same-priority streams)")
+    out.append("## Solve-kernel dispatches (persistent: one per N-class, concurrent on three streams; grid = the class's share of the SIMD slots)")
     out.append("")
-    out.append("| kernel | queue | start ms | duration ms | trajectories | LDS B | scratch B/lane | arch VGPR | AGPR | SGPR |")
+    out.append("| kernel | queue | start ms | duration ms | workgroups | LDS B | scratch B/lane | arch VGPR | AGPR | SGPR |")
     out.append("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
     for r in rows:
         out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {(r[2] - t0) / 1e6:.1f} | {r[4] / 1e6:.1f} | {r[5] // 64} | {r[6]} | "
@@ -60,6 +60,33 @@ def main(src, dst, tag):
                    f"(HIP events on the launch stream), value = {b['value']:.1f} {b['unit']}")
     except Exception as ex:  # noqa: BLE001
         out.append(f"- (bench output not parsed: {ex})")
+    # the default, pipelined command
+    kt2 = os.path.join(src, "kt2", "kt_results.db")
+    if os.path.exists(kt2):
+        cols, rows2 = q(kt2, "select name, queue_id, start, end, duration, grid_x from kernels where name like 'k_solve%' order by start")
+        t0 = rows2[0][2]
+        out.append("")
+        out.append("## Default command (two batches in flight): rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial")
+        out.append("")
+        out.append("Launches of consecutive steps overlap: a batch's workgroups take the SIMDs the previous batch's exiting workgroups free.")
+        out.append("")
+        out.append("| kernel | queue | start ms | end ms | duration ms | workgroups |")
+        out.append("|---|---:|---:|---:|---:|---:|")
+        for r in rows2:
+            out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {(r[2] - t0) / 1e6:.1f} | {(r[3] - t0) / 1e6:.1f} | {r[4] / 1e6:.1f} | {r[5] // 64} |")
+        ends = sorted(r[3] for r in rows2)
+        # one step = three launches; the step's end = its last launch's end
+        by_step = [max(r[3] for r in rows2[i:i + 3]) for i in range(0, len(rows2) - len(rows2) % 3, 3)]
+        if len(by_step) > 2:
+            cad = [(b - a) / 1e6 for a, b in zip(by_step[1:-1], by_step[2:])]
+            out.append("")
+            out.append(f"- time between the ends of consecutive timed steps: {', '.join(f'{c:.0f}' for c in cad)} ms")
+        try:
+            b = json.loads(open(os.path.join(src, "bench_kt2.json")).read().strip().splitlines()[-1])
+            out.append(f"- bench.py under the profiler: value = {b['value']:.1f} {b['unit']}, ms_per_step = {b['ms_per_step']:.1f}, "
+                       f"event spans of the steps = {[round(x) for x in b['roofline']['kernel_span_ms_each']]}")
+        except Exception as ex:  # noqa: BLE001
+            out.append(f"- (bench output not parsed: {ex})")
     # PMC
     tot = {}
     for nm, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
