@@ -227,3 +227,33 @@ def test_optimizer_yaml_parameters_are_wired_not_hard_coded(cuboids_small):
         if abs(f - f_base[stage]) > 1e-9 * abs(f):
             moved += 1
     assert moved >= len(names) - 2     # at this point nearly every term is active
+
+
+def test_persistent_queue_loop_in_the_emulator(cuboids_small, monkeypatch):
+    """The emulated device has 8 SIMD slots (tests/emu): 18 candidates of mixed classes are drained by workgroups that
+    loop over their class's queue; the capped solves must equal the one-workgroup-per-candidate launch bit for bit."""
+    cs = cuboids_small
+    sel = [0, 1, 2, 3, 4, 5] * 3
+    lens = cs["lens"][sel]
+    paths = np.concatenate([cs["paths"][cs["offs"][i]:cs["offs"][i + 1]] for i in sel])
+
+    def solve():
+        p = api.default_params(api.load(EMU_LIB))
+        p.s1_lbfgs.max_iterations = 6
+        p.s2_lbfgs.max_iterations = 4
+        p.alm_max_outer = 1
+        opt = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+        set_map(opt, cs["world"])
+        opt.optimizeTraj(lens, paths)
+        return opt.stats().copy(), opt.traj_cost.copy(), [opt.get_x(k) for k in range(len(sel))]
+
+    monkeypatch.setenv("TOPAY_PERSISTENT", "0")
+    st0, c0, x0 = solve()
+    monkeypatch.setenv("TOPAY_PERSISTENT", "1")
+    st1, c1, x1 = solve()
+    assert (st0 == st1).all() and (c0 == c1).all()
+    for a, b in zip(x0, x1):
+        assert (a == b).all()
+    # the three copies of every candidate are identical too (a workgroup's LDS state does not leak into its next candidate)
+    for k in range(6):
+        assert (x1[k] == x1[k + 6]).all() and (x1[k] == x1[k + 12]).all() and c1[k] == c1[k + 6] == c1[k + 12]

@@ -357,7 +357,7 @@ def test_capped_solves_of_long_trajectories_are_bit_identical_to_emulator():
 
 def test_two_batches_in_flight_give_the_serial_results():
     """topay_optimize_async / topay_synchronize: two contexts issued back to back on one GPU return exactly what a
-    serial solve returns (no cross-talk through the shared bucket streams or the shared parameter block)."""
+    serial solve returns (no cross-talk through the dispatch gate or the shared parameter block)."""
     tb = wl.TablesBatch(16, 8, base_seed=4242, nthreads=8)
     half = len(tb.lens) // 2
     offs = np.concatenate([[0], np.cumsum(tb.lens)])
@@ -385,4 +385,38 @@ def test_two_batches_in_flight_give_the_serial_results():
     for (ok_s, c_s, st_s), (ok_p, c_p, st_p) in zip(serial, res):
         assert (ok_s == ok_p).all() and (st_s == st_p).all()
         assert ((c_s == c_p) | (np.isnan(c_s) & np.isnan(c_p))).all()
+    tb.close()
+
+
+@pytest.mark.gpu
+def test_persistent_queues_do_not_change_results(monkeypatch):
+    """The persistent launch (resident workgroups taking candidates from a queue; which wave solves which candidate is
+    timing-dependent) returns bit for bit what the one-workgroup-per-candidate launch returns.  1536 candidates on 1024
+    SIMD slots, so every queue is really drained by looping workgroups."""
+    tb = wl.TablesBatch(192, 8, base_seed=777, nthreads=8)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+
+    def solve():
+        o = api.MomaTrajOptBatch(device=0)
+        for s in tb.scenarios:
+            set_map(o, tb.world(s), map_id=slot[s])
+        o.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+        ok = o.optimize()
+        out = (ok.copy(), o.traj_cost.copy(), o.stats(), o.total_durations(), [o.get_x(b) for b in (0, 500, 1535)])
+        o.close()
+        return out
+
+    monkeypatch.setenv("TOPAY_PERSISTENT", "0")
+    ref = solve()
+    monkeypatch.setenv("TOPAY_PERSISTENT", "1")
+    per = solve()
+    per2 = solve()
+    for got in (per, per2):
+        assert (ref[0] == got[0]).all() and (ref[2] == got[2]).all()
+        assert ((ref[1] == got[1]) | (np.isnan(ref[1]) & np.isnan(got[1]))).all()
+        assert ((ref[3] == got[3]) | (np.isnan(ref[3]) & np.isnan(got[3]))).all()
+        for xa, xb in zip(ref[4], got[4]):
+            assert (xa == xb).all()
+    assert ref[0].mean() > 0.8
     tb.close()
