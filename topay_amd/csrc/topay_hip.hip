@@ -540,10 +540,6 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->simd_slots = 4 * prop.multiProcessorCount;   // one wave per SIMD (TOPAY_WAVES_PER_EU = 1), four SIMDs per CU
-    // a few slots stay free for the small kernels other libraries launch while a solve is resident (torch fills and
-    // copies, the RCCL gather of the result records): with every slot taken they would wait for a workgroup to exit
-    const char* rs = getenv("TOPAY_RESERVE_SLOTS");
-    c->simd_slots = std::max(64, c->simd_slots - (rs ? atoi(rs) : 0));
   }
   {
     const char* g = getenv("TOPAY_DISPATCH_GATE");
