@@ -117,7 +117,17 @@ def main():
         tb.world = lambda s_: hw
         tb_map_of = np.zeros(len(tb.lens), dtype=np.int32)
     else:
-        tb = wl.TablesBatch(S, Ccand, base_seed=42 + rank * 100000, nthreads=0)
+        # host side of the generator: as many threads as this rank may use, and only the scenarios the CPU baseline
+        # solves keep their CPU-built 3-D distance field (the device builds its own from the occupancy grids): 1 GB
+        # instead of 5.5 GB of host memory per rank
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) if distributed else 1
+        gen_threads = max(1, host_cores() // max(1, local_world))
+        keep = None
+        if distributed or args.no_cpu_baseline:
+            keep = 0
+        else:
+            keep = min(S, (args.cpu_sample + Ccand - 1) // Ccand + 32)
+        tb = wl.TablesBatch(S, Ccand, base_seed=42 + rank * 100000, nthreads=gen_threads, keep_esdf3d=keep)
     B = len(tb.lens)
     # `--inflight` contexts hold the same batch (in a sweep they would hold consecutive batches): step i runs on context
     # i mod inflight, so the tail of one step -- a few long candidates, most SIMDs idle -- overlaps the bulk of the next.

@@ -52,3 +52,22 @@ def test_tables_batch_one_map_per_scenario():
     w0, w1 = tb.world(0), tb.world(1)
     assert not (w0.esdf2d == w1.esdf2d).all()
     tb.close()
+
+
+def test_tables_batch_can_drop_cpu_esdf3d_without_changing_the_inputs():
+    """bench.py keeps the CPU-built 3-D distance field only for the scenarios the CPU baseline solves; paths, occupancy
+    grids and the 2-D field must not depend on that."""
+    from topay_amd.harness import workload as wl
+
+    a = wl.TablesBatch(4, 2, base_seed=4242, nthreads=4)
+    b = wl.TablesBatch(4, 2, base_seed=4242, nthreads=4, keep_esdf3d=1)
+    assert (a.lens == b.lens).all() and (a.paths == b.paths).all() and (a.scen == b.scen).all()
+    for s in a.scenarios:
+        wa, wb = a.world(s), b.world(s)
+        assert (wa.occ3d == wb.occ3d).all() and (wa.occ2d == wb.occ2d).all() and (wa.esdf2d == wb.esdf2d).all()
+        if s < 1:
+            assert (wa.esdf3d == wb.esdf3d).all()
+        else:
+            assert wb.esdf3d is None
+    a.close()
+    b.close()

@@ -40,6 +40,9 @@ def lib():
         L.wl_world_occ2d.argtypes = [C.c_void_p]
         L.wl_world_occ3d.argtypes = [C.c_void_p]
         L.wl_world_esdf3d.argtypes = [C.c_void_p]
+        L.wl_world_esdf3d_size.argtypes = [C.c_void_p]
+        L.wl_world_esdf3d_size.restype = C.c_longlong
+        L.wl_set_keep_esdf3d.argtypes = [C.c_int]
         L.wl_world_destroy.argtypes = [C.c_void_p]
         L.wl_world_desc.argtypes = [C.c_void_p, c_ip, c_dp, c_dp, c_dp, c_dp]
         L.wl_sample_start_goal_xy.argtypes = [C.c_uint64, C.c_double, c_dp, c_dp]
@@ -88,7 +91,8 @@ class World:
         n2 = int(dims[0]) * int(dims[1])
         n3 = n2 * int(dims[2])
         self.esdf2d = np.ctypeslib.as_array(L.wl_world_esdf2d(self.h), shape=(n2,))
-        self.esdf3d = np.ctypeslib.as_array(L.wl_world_esdf3d(self.h), shape=(n3,))
+        # None when the batch generator was told to drop it (TablesBatch(keep_esdf3d=...))
+        self.esdf3d = np.ctypeslib.as_array(L.wl_world_esdf3d(self.h), shape=(n3,)) if L.wl_world_esdf3d_size(self.h) == n3 else None
         self.occ2d = np.ctypeslib.as_array(L.wl_world_occ2d(self.h), shape=(n2,))
         self.occ3d = np.ctypeslib.as_array(L.wl_world_occ3d(self.h), shape=(n3,))
 
@@ -189,9 +193,16 @@ def cuboids_batch(n_scenarios, n_cand, map_seed=42, base_seed=42, first_scenario
 class TablesBatch:
     """S 'tables' scenarios, one map each, n_cand candidates per scenario (benchmark_tables batch)."""
 
-    def __init__(self, n_scenarios, n_cand, base_seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, nthreads=0):
+    def __init__(self, n_scenarios, n_cand, base_seed=42, size_xy=20.0, size_z=1.6, res=0.1, cloud_res=0.05, nthreads=0,
+                 keep_esdf3d=None):
+        """keep_esdf3d = k: only the first k scenarios keep their CPU-built 3-D distance field (World.esdf3d is None for
+        the others); the occupancy grids and the 2-D field are always kept."""
         L = lib()
-        self.h = C.c_void_p(L.wl_tables_batch_create(n_scenarios, n_cand, base_seed, size_xy, size_z, res, cloud_res, nthreads))
+        L.wl_set_keep_esdf3d(-1 if keep_esdf3d is None else int(keep_esdf3d))
+        try:
+            self.h = C.c_void_p(L.wl_tables_batch_create(n_scenarios, n_cand, base_seed, size_xy, size_z, res, cloud_res, nthreads))
+        finally:
+            L.wl_set_keep_esdf3d(-1)
         nt = L.wl_tables_batch_ntraj(self.h)
         ns = L.wl_tables_batch_nstates(self.h)
         self.lens = np.zeros(nt, dtype=np.int32)

@@ -102,6 +102,13 @@ struct TablesBatch {
   std::vector<double> paths;      // ragged
 };
 
+// Scenarios with index >= g_keep_esdf3d drop their CPU-built 3-D distance field as soon as their init paths exist (it
+// is only needed to sample the arm poses and by callers that hand the field to a CPU solver); -1 keeps all.  Saves
+// 5 MB per scenario of host memory when the product builds the fields on the device from the occupancy grids.
+static int g_keep_esdf3d = -1;
+void wl_set_keep_esdf3d(int keep) { g_keep_esdf3d = keep; }
+long long wl_world_esdf3d_size(void* h) { return (long long)((World*)h)->gm.esdf3d.size(); }
+
 void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_xy, double size_z, double res,
                              double cloud_res, int nthreads) {
   TablesBatch* tb = new TablesBatch();
@@ -136,6 +143,7 @@ void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_
         std::vector<int> ln;
         if (ok) ok = w->initPaths(start, goal, n_cand, seed * 104729 + attempt, pth, ln) == n_cand;
         if (!ok) { delete w; continue; }
+        if (g_keep_esdf3d >= 0 && sidx >= g_keep_esdf3d) std::vector<double>().swap(w->gm.esdf3d);
         tb->worlds[sidx] = w;
         for (int q = 0; q < 10; q++) { tb->starts[sidx][q] = start[q]; tb->goals[sidx][q] = goal[q]; }
         lens[sidx] = ln;
