@@ -420,3 +420,41 @@ def test_persistent_queues_do_not_change_results(monkeypatch):
             assert (xa == xb).all()
     assert ref[0].mean() > 0.8
     tb.close()
+
+
+@pytest.mark.gpu
+def test_contexts_with_different_parameters_in_flight():
+    """The kernels read the parameters from one __constant__ block: two contexts with different parameters must not
+    overlap on the device (the library makes the second wait), and each must return its own serial result."""
+    tb = wl.TablesBatch(8, 8, base_seed=999, nthreads=8)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+    lib = api.load()
+    pa = api.default_params(lib)
+    pb = api.default_params(lib)
+    pb.s2_lbfgs.max_iterations = 15
+    pb.alm_max_outer = 1
+    pb.s2_time_weight = 80.0            # a weight the kernels read from the constant block throughout the solve
+
+    def make(p):
+        o = api.MomaTrajOptBatch(params=p, device=0)
+        for s in tb.scenarios:
+            set_map(o, tb.world(s), map_id=slot[s])
+        o.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+        return o
+
+    serial = []
+    for p in (pa, pb):
+        o = make(p)
+        ok = o.optimize()
+        serial.append((ok.copy(), o.traj_cost.copy(), o.stats()))
+        o.close()
+    assert (serial[0][2] != serial[1][2]).any()          # the two parameter sets really behave differently
+    a, b = make(pa), make(pb)
+    a.optimize_async()
+    b.optimize_async()
+    got = [(a.finish(), a.traj_cost.copy(), a.stats()), (b.finish(), b.traj_cost.copy(), b.stats())]
+    for (ok_s, c_s, st_s), (ok_p, c_p, st_p) in zip(serial, got):
+        assert (ok_s == ok_p).all() and (st_s == st_p).all()
+        assert ((c_s == c_p) | (np.isnan(c_s) & np.isnan(c_p))).all()
+    tb.close()

@@ -331,6 +331,9 @@ __attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU
 // Dispatch gate (topay_optimize_async): the context whose solve was issued last in this process.
 struct topay_ctx;
 static std::mutex g_issue_mutex;
+// Every live context of the process (topay_create / topay_destroy), for push_params.
+static std::mutex g_registry_mutex;
+static std::vector<topay_ctx*> g_contexts;
 static topay_ctx* g_last_issued = nullptr;
 
 struct topay_ctx {
@@ -551,12 +554,20 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    g_contexts.push_back(c);
+  }
   *out = c;
   return TOPAY_OK;
 }
 
 void topay_destroy(topay_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
+  }
   (void)hipSetDevice(c->device);
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
@@ -614,7 +625,15 @@ static int bucket_of(int N) {
 static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256) * sizeof(double); }
 
 static topay_status push_params(topay_ctx* c) {
-  // contexts of one process may carry different parameters: refresh the constant block before every launch
+  // Contexts of one process may carry different parameters, and the kernels read them from one __constant__ block for
+  // as long as they run: refresh it before every launch, and if a solve of another context with *different*
+  // parameters is still in flight on this device, let it finish first (contexts with equal parameters overlap freely).
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    for (topay_ctx* q : g_contexts)
+      if (q != c && q->pending && q->device == c->device && memcmp(&q->dp, &c->dp, sizeof(DevParams)) != 0)
+        HIPCHK(hipStreamSynchronize(q->stream));
+  }
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_P), &c->dp, sizeof(DevParams), 0, hipMemcpyHostToDevice, c->stream));
   return TOPAY_OK;
 }
