@@ -100,3 +100,12 @@ def test_cpp_caller_runs_on_the_device(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("candidate")]
     assert len(lines) == 2 and all("success 1" in ln for ln in lines)
+
+
+def test_header_is_plain_c99():
+    """The boundary is a C ABI: include/topay.h must compile as C (a cgo / JNI / ctypes generator reads it as such)."""
+    import subprocess
+
+    src = '#include "topay.h"\nint main(void) { topay_params_t p; return (int)sizeof(p) == 0; }\n'
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c", "-"],
+                   input=src, text=True, check=True)
