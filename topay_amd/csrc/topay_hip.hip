@@ -183,13 +183,16 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
     return;
   }
-  for (;;) {
-    int pos = 0;
-    if (threadIdx.x == 0) pos = atomicAdd(Bt.queue_next, 1);
-    pos = __shfl(pos, 0);
-    if (pos >= Bt.queue_count) break;
-    solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[pos]);
-    __syncthreads();
+  for (int cls = Bt.queue_class; cls >= 0; cls--) {
+    const int count = Bt.queue_count[cls], off = Bt.queue_off[cls];
+    for (;;) {
+      int pos = 0;
+      if (threadIdx.x == 0) pos = atomicAdd(Bt.queue_next + cls, 1);
+      pos = __shfl(pos, 0);
+      if (pos >= count) break;
+      solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[off + pos]);
+      __syncthreads();
+    }
   }
 }
 
@@ -617,9 +620,14 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
 }
 
 static int bucket_of(int N) {
+  // diagnostic (tests): TOPAY_FORCE_CLASS=2|3 sends every candidate that fits through the kernel with 2 | 3 rows per lane
+  static const int force = [] { const char* f = getenv("TOPAY_FORCE_CLASS"); return f ? atoi(f) : 0; }();
+  int k0 = 0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
-    if (N <= kBucketMaxN[k]) return k;
-  return topay_ctx::NBUCKET - 1;
+    if (N <= kBucketMaxN[k]) { k0 = k; break; }
+  if (N > kBucketMaxN[topay_ctx::NBUCKET - 1]) k0 = topay_ctx::NBUCKET - 1;
+  if (force >= 2 && force <= topay_ctx::NBUCKET) k0 = std::max(k0, force - 1);
+  return k0;
 }
 // + past-cost ring [8] + two-loop alpha ring [256]
 static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256) * sizeof(double); }
@@ -945,13 +953,20 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2
     for (int b : v) nm = std::max(nm, c->hN[b]);
     DevBatch d = c->db;
     d.order = c->db.order + off;
-    off += nk;
     int grid = nk;
     if (persistent) {
-      d.queue_next = c->qnext.as<int>() + k;
-      d.queue_count = nk;
+      d.order = c->db.order;
+      d.queue_next = c->qnext.as<int>();
+      d.queue_class = k;
+      int o2 = 0;
+      for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {   // `order` holds the classes largest first
+        d.queue_off[kk] = o2;
+        d.queue_count[kk] = (int)c->cls[kk].size();
+        o2 += d.queue_count[kk];
+      }
       grid = share[k];
     }
+    off += nk;
     const size_t lds = solve_lds_bytes(nm);
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));

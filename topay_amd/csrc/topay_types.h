@@ -105,8 +105,12 @@ struct DevBatch {
   double* fout;       // [B] eval hook output
   double* sbuf;       // [B][14][13*Nmax] per-sample gradient rows parked between the cost and the gradient phase
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
-  int* queue_next;    // persistent launches: next position of `order` to hand out (device counter); null = one workgroup per position
-  int queue_count;    // positions of `order` this launch owns
+  // persistent launches: one queue per N-class = positions [queue_off[k], queue_off[k] + queue_count[k]) of `order`, handed
+  // out through the device counters queue_next[k]; a workgroup of class queue_class drains its own queue, then the
+  // queues of the smaller classes (its kernel template and LDS cover them, and results do not depend on the template).
+  // queue_next == null: one workgroup per position of `order`.
+  int* queue_next;
+  int queue_count[3], queue_off[3], queue_class;
   int* started;       // one counter in pinned host memory: candidates of this launch that have begun (dispatch gate; may be null)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
   double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
