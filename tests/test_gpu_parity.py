@@ -458,3 +458,68 @@ def test_contexts_with_different_parameters_in_flight():
         assert (ok_s == ok_p).all() and (st_s == st_p).all()
         assert ((c_s == c_p) | (np.isnan(c_s) & np.isnan(c_p))).all()
     tb.close()
+
+
+@pytest.mark.gpu
+def test_chained_batches_give_the_serial_results(monkeypatch):
+    """TOPAY_CHAIN=1: resident workgroups go on with the next published batch instead of exiting (the init step runs
+    inside the solve, completion is a counter in pinned memory).  Three contexts, seven batches in flight three deep:
+    every batch must return exactly what the default launch returns for the same inputs, also after a chain has ended
+    (synchronous solve in between) and with a context whose parameters differ (which ends the chain)."""
+    tb = wl.TablesBatch(160, 8, base_seed=31337, nthreads=8)       # 1280 candidates: more than the 1024 SIMD slots
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+
+    def make(p=None):
+        o = api.MomaTrajOptBatch(params=p, device=0)
+        for s in tb.scenarios:
+            set_map(o, tb.world(s), map_id=slot[s])
+        o.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+        return o
+
+    def result(o):
+        return o.finish().copy(), o.traj_cost.copy(), o.stats().copy(), o.total_durations().copy()
+
+    def same(a, b):
+        return ((a[0] == b[0]).all() and (a[2] == b[2]).all() and ((a[1] == b[1]) | (np.isnan(a[1]) & np.isnan(b[1]))).all()
+                and ((a[3] == b[3]) | (np.isnan(a[3]) & np.isnan(b[3]))).all())
+
+    monkeypatch.delenv("TOPAY_CHAIN", raising=False)
+    ref = make()
+    ref.optimize_async()
+    want = result(ref)
+    lib = api.load()
+    p2 = api.default_params(lib)
+    p2.s2_lbfgs.max_iterations = 10
+    p2.alm_max_outer = 1
+    ref2 = make(p2)
+    ref2.optimize_async()
+    want2 = result(ref2)
+    ref.close()
+    ref2.close()
+
+    monkeypatch.setenv("TOPAY_CHAIN", "1")
+    ctxs = [make() for _ in range(3)]
+    got = []
+    for i in range(7):
+        o = ctxs[i % 3]
+        if i >= 3:
+            got.append(result(o))
+        o.reset()
+        o.optimize_async()
+    for i in range(4, 7):
+        got.append(result(ctxs[i % 3]))
+    assert len(got) == 7 and all(same(want, g) for g in got)
+    # a lone synchronous solve after the chain has ended, then a context with other parameters, then the default again
+    ctxs[0].reset()
+    assert same(want, (ctxs[0].optimize().copy(), ctxs[0].traj_cost.copy(), ctxs[0].stats().copy(), ctxs[0].total_durations().copy()))
+    other = make(p2)
+    ctxs[1].reset()
+    ctxs[1].optimize_async()
+    other.optimize_async()
+    ctxs[2].reset()
+    ctxs[2].optimize_async()
+    assert same(want, result(ctxs[1])) and same(want2, result(other)) and same(want, result(ctxs[2]))
+    for o in ctxs + [other]:
+        o.close()
+    tb.close()

@@ -104,9 +104,21 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
   }
 }
 
+__device__ __noinline__ void init_candidate(const DevBatch& Bt, int b) {
+  init_one(g_P, Bt.in_paths + Bt.in_off[b] * 10, Bt.in_len[b], Bt.in_bvel + (size_t)b * 20, Bt.in_bacc + (size_t)b * 20,
+           Bt.in_scratch + (size_t)b * Bt.in_scratch_stride, Bt.in_maxN, Bt.N + b, Bt.s1_past + b, Bt.head + (size_t)b * 27,
+           Bt.tail + (size_t)b * 27, Bt.start_xy + 2 * b, Bt.goal_xy + 2 * b, Bt.init_xy + (size_t)b * 2 * Bt.in_maxN,
+           Bt.x0 + (size_t)b * Bt.in_stride_n);
+}
+
 template <int RMAX>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N, int b) {
   const unsigned long long t_begin = wall_clock64();
+  if (Bt.in_paths) {  // optimizeTraj:146-357 for this candidate (one lane; the result is what the init kernel writes)
+    if (threadIdx.x == 0) init_candidate(Bt, b);
+    __threadfence();
+    __syncthreads();
+  }
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
   // is resident, see topay_optimize_async
   if (threadIdx.x == 0 && Bt.started) {
@@ -169,6 +181,16 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
     Bt.hw_id[b] = 0;
 #endif
   }
+  if (Bt.chain) {
+    // completion signal of a chained batch: results first (release at system scope), then the count
+#ifndef TOPAY_CPU_EMU
+    __threadfence_system();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(&Bt.chain->finished[Bt.chain_gen & (TOPAY_CHAIN_SLOTS - 1)], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    if (threadIdx.x == 0) Bt.chain->finished[Bt.chain_gen & (TOPAY_CHAIN_SLOTS - 1)] += 1;
+#endif
+  }
 }
 
 // Persistent launch: the grid is one workgroup per SIMD slot (or fewer), and every workgroup takes candidates from the
@@ -183,16 +205,60 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
     return;
   }
-  for (int cls = Bt.queue_class; cls >= 0; cls--) {
-    const int count = Bt.queue_count[cls], off = Bt.queue_off[cls];
-    for (;;) {
-      int pos = 0;
-      if (threadIdx.x == 0) pos = atomicAdd(Bt.queue_next + cls, 1);
-      pos = __shfl(pos, 0);
-      if (pos >= count) break;
-      solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[off + pos]);
-      __syncthreads();
+  const int my_class = Bt.queue_class;
+  DevBatch cur = Bt;
+  const DevMap* cmaps = maps;
+  for (;;) {
+    for (int cls = my_class; cls >= 0; cls--) {
+      const int count = cur.queue_count[cls], off = cur.queue_off[cls];
+      for (;;) {
+        int pos = 0;
+        if (threadIdx.x == 0) {
+#ifndef TOPAY_CPU_EMU
+          // chained batches keep their counters in the pinned control block: system scope
+          pos = cur.chain ? __hip_atomic_fetch_add(cur.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                          : atomicAdd(cur.queue_next + cls, 1);
+#else
+          pos = atomicAdd(cur.queue_next + cls, 1);
+#endif
+        }
+        pos = __shfl(pos, 0);
+        if (pos >= count) break;
+        solve_one<RMAX>(cur, cmaps, Nmax_lds, init_stride_N, cur.order[off + pos]);
+        __syncthreads();
+      }
     }
+    // out of work in this batch: go on with the next one if the host has published it (ChainCtl), else end the chain
+    ChainCtl* ch = cur.chain;
+    if (!ch) break;
+    const int gen = cur.chain_gen;
+    int st = 0;
+    if (threadIdx.x == 0) {
+#ifndef TOPAY_CPU_EMU
+      st = __hip_atomic_load(&ch->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (st == gen) {
+        int expected = gen;
+        if (__hip_atomic_compare_exchange_strong(&ch->state, &expected, -2 - gen, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM)) st = -2 - gen;
+        else st = expected;   // the host has just published gen + 1 (or another workgroup ended the chain)
+      }
+#else
+      st = ch->state;
+      if (st == gen) { ch->state = -2 - gen; st = -2 - gen; }
+#endif
+    }
+    st = __shfl(st, 0);
+    // newest published generation, whether the chain is still open (st >= 0) or ended (st = -2 - newest): a workgroup
+    // that lags behind still has to serve every generation that was published before the chain ended
+    const int newest = st >= 0 ? st : -2 - st;
+    if (newest <= gen) break;
+#ifndef TOPAY_CPU_EMU
+    __threadfence_system();
+#endif
+    const ChainDesc* nd = &ch->desc[(gen + 1) & (TOPAY_CHAIN_SLOTS - 1)];
+    cur = nd->d;
+    cmaps = nd->maps;
+    __syncthreads();
   }
 }
 
@@ -337,6 +403,27 @@ static std::mutex g_issue_mutex;
 // Every live context of the process (topay_create / topay_destroy), for push_params.
 static std::mutex g_registry_mutex;
 static std::vector<topay_ctx*> g_contexts;
+
+// Host side of batch chaining (ChainCtl, topay_types.h): per device two control blocks / stream sets used alternately by
+// successive chains, so that a new chain can start while the workgroups of a chain that has just ended finish their
+// last candidates.
+struct ChainHost {
+  bool inited = false;
+  ChainCtl* h[2] = {nullptr, nullptr};   // pinned host memory
+  ChainCtl* d[2] = {nullptr, nullptr};   // the same blocks as the device sees them
+  hipStream_t st[2][3] = {{nullptr}};
+  hipEvent_t start_ev[2] = {nullptr, nullptr};
+  int set = 0;
+  bool alive = false;
+  int gen = 0;                           // latest generation published (or launched) on the current set
+  int nm[3] = {0, 0, 0};                 // LDS sizing (max N) of the running kernels per class
+  bool has[3] = {false, false, false};
+  DevParams dp;
+  int n_of_slot[TOPAY_CHAIN_SLOTS] = {0};
+  topay_ctx* owner[TOPAY_CHAIN_SLOTS] = {nullptr};   // context whose batch used the slot last, and that batch's generation
+  int owner_gen[TOPAY_CHAIN_SLOTS] = {0};
+};
+static ChainHost g_chain[16];
 static topay_ctx* g_last_issued = nullptr;
 
 struct topay_ctx {
@@ -364,6 +451,10 @@ struct topay_ctx {
   int n_launched = 0;        // candidates the pending solve launched
   bool gate = true;
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
+  bool chain_enabled = false;  // TOPAY_CHAIN: resident workgroups go on with the next published batch instead of exiting
+  bool chained_mode = false;   // the pending solve signals completion through the chain's counter, not through the stream
+  bool done_observed = false;  // ... and somebody has already seen that counter reach n_launched
+  int chain_set = 0, chain_gen = 0;
   int simd_slots = 1024;
   DevBuf qnext;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
@@ -541,6 +632,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     HIPCHK(hipEventCreate(&c->bevent[k]));
   }
   {
+    { const char* ce = getenv("TOPAY_CHAIN"); c->chain_enabled = ce && ce[0] == '1'; }
     const char* pe = getenv("TOPAY_PERSISTENT");
     c->persistent = !(pe && pe[0] == '0');
     hipDeviceProp_t prop;
@@ -567,6 +659,13 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
 
 void topay_destroy(topay_ctx* c) {
   if (!c) return;
+  if (c->pending) (void)topay_synchronize(c);   // a chained batch may still be read by resident workgroups
+  {
+    std::lock_guard<std::mutex> lk(g_issue_mutex);
+    ChainHost& ch = g_chain[c->device % 16];
+    for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++)
+      if (ch.owner[q] == c) ch.owner[q] = nullptr;
+  }
   {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
     g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
@@ -632,6 +731,10 @@ static int bucket_of(int N) {
 // + past-cost ring [8] + two-loop alpha ring [256]
 static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256) * sizeof(double); }
 
+static bool batch_done(topay_ctx* p);
+// what the __constant__ parameter block of each device holds (last push)
+static DevParams g_pushed_dp[16];
+static bool g_pushed_valid[16] = {false};
 static topay_status push_params(topay_ctx* c) {
   // Contexts of one process may carry different parameters, and the kernels read them from one __constant__ block for
   // as long as they run: refresh it before every launch, and if a solve of another context with *different*
@@ -639,10 +742,19 @@ static topay_status push_params(topay_ctx* c) {
   {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
     for (topay_ctx* q : g_contexts)
-      if (q != c && q->pending && q->device == c->device && memcmp(&q->dp, &c->dp, sizeof(DevParams)) != 0)
-        HIPCHK(hipStreamSynchronize(q->stream));
+      if (q != c && q->pending && q->device == c->device && memcmp(&q->dp, &c->dp, sizeof(DevParams)) != 0) {
+        if (q->chained_mode) {   // its kernels are not on its stream: wait for the batch's completion counter
+          const auto t0 = std::chrono::steady_clock::now();
+          while (!batch_done(q) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(600))
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        } else {
+          HIPCHK(hipStreamSynchronize(q->stream));
+        }
+      }
   }
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_P), &c->dp, sizeof(DevParams), 0, hipMemcpyHostToDevice, c->stream));
+  g_pushed_dp[c->device % 16] = c->dp;
+  g_pushed_valid[c->device % 16] = true;
   return TOPAY_OK;
 }
 
@@ -895,6 +1007,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.hw_id = c->hwid.as<int>();
   HIPCHK(hipMemsetAsync(c->elapsed.p, 0, (size_t)batch * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)batch * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)batch * 8, c->stream));   // never-launched candidates: cost = NaN
   HIPCHK(hipMemsetAsync(c->stats.p, 0, (size_t)batch * 32, c->stream));
   c->have_traj = true;
   return TOPAY_OK;
@@ -904,10 +1017,32 @@ topay_status topay_reset(topay_ctx* c) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   c->solved = false;
+  if (c->chain_enabled && c->persistent) return TOPAY_OK;   // chained batches initialise inside the solve (DevBatch::in_paths)
   return run_init(c);
 }
 
 }  // extern "C"
+
+// Persistent grids: the slots are divided between the classes in proportion to an estimate of their work
+// (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly), so that the launches of
+// one batch together ask for exactly the slots the device has and none of their workgroups waits in the dispatcher.
+static void compute_shares(topay_ctx* c, int slots, int* share) {
+  double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
+  for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+    for (int b : c->cls[k]) wk[k] += std::pow((double)c->hN[b], 1.5);
+    wt += wk[k];
+  }
+  int used = 0;
+  for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+    const int nk = (int)c->cls[k].size();
+    share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
+    used += share[k];
+  }
+  for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
+    const int kk = k % topay_ctx::NBUCKET;
+    if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
+  }
+}
 
 template <typename KF1, typename KF2, typename KF3, typename... Args>
 static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2, KF3 k3, Args... args) {
@@ -923,27 +1058,8 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2
     HIPCHK(hipMemsetAsync(c->qnext.p, 0, sizeof(int) * topay_ctx::NBUCKET, c->stream));
     slots = c->simd_slots;
   }
-  // Persistent grids: the slots are divided between the classes in proportion to an estimate of their work
-  // (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly), so that the launches of
-  // one batch together ask for exactly the slots the device has and none of their workgroups waits in the dispatcher.
   int share[topay_ctx::NBUCKET] = {0};
-  if (persistent) {
-    double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
-    for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-      for (int b : c->cls[k]) wk[k] += std::pow((double)c->hN[b], 1.5);
-      wt += wk[k];
-    }
-    int used = 0;
-    for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-      const int nk = (int)c->cls[k].size();
-      share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
-      used += share[k];
-    }
-    for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
-      const int kk = k % topay_ctx::NBUCKET;
-      if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
-    }
-  }
+  if (persistent) compute_shares(c, slots, share);
   HIPCHK(hipEventRecord(c->bstart, c->stream));  // params + resets on the main stream come first
   for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
     const std::vector<int>& v = c->cls[k];
@@ -990,6 +1106,206 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2
   return TOPAY_OK;
 }
 
+
+// ---- batch chaining (TOPAY_CHAIN=1) ---------------------------------------------------------------------------
+static bool batch_done(topay_ctx* p) {
+  if (!p->pending) return true;
+  if (p->chained_mode) {
+    if (p->done_observed) return true;
+    ChainHost& ch = g_chain[p->device % 16];
+    volatile int* f = &ch.h[p->chain_set]->finished[p->chain_gen & (TOPAY_CHAIN_SLOTS - 1)];
+    return *f >= p->n_launched;
+  }
+  return hipStreamQuery(p->stream) == hipSuccess;
+}
+
+static topay_status chain_init(ChainHost& ch) {
+  if (ch.inited) return TOPAY_OK;
+  for (int s_ = 0; s_ < 2; s_++) {
+    void* hp = nullptr;
+    HIPCHK(hipHostMalloc(&hp, sizeof(ChainCtl), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(hp, 0, sizeof(ChainCtl));
+    ch.h[s_] = (ChainCtl*)hp;
+    ch.h[s_]->state = -1;
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
+    ch.d[s_] = (ChainCtl*)dp;
+    for (int k = 0; k < 3; k++) HIPCHK(hipStreamCreateWithFlags(&ch.st[s_][k], hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ch.start_ev[s_]));
+  }
+  ch.inited = true;
+  return TOPAY_OK;
+}
+
+static int host_load(int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static bool host_cas(int* p, int expected, int desired) {
+  return __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+}
+
+// Issues the solve of context c either by publishing its batch to the running chain (no launch: the resident
+// workgroups pick it up when they run out of work) or by launching a new chain.  Called with g_issue_mutex held.
+static topay_status issue_chained(topay_ctx* c) {
+  ChainHost& ch = g_chain[c->device % 16];
+  topay_status cs = chain_init(ch);
+  if (cs != TOPAY_OK) return cs;
+  // Batch-side preparation without a single device operation (a device occupied by resident workgroups runs nothing
+  // else, not even a small copy kernel): the queue counters live in the pinned control block, the parameter block is
+  // only rewritten when it does not hold this batch's parameters (which ends a running chain anyway), candidates that are never launched keep the
+  // success = 0 / cost = NaN that topay_set_init_traj wrote, and the init step runs inside the solve.
+  if (!(g_pushed_valid[c->device % 16] && memcmp(&g_pushed_dp[c->device % 16], &c->dp, sizeof(DevParams)) == 0)) {
+    topay_status ps = push_params(c);   // (what the constant block holds is not what this batch needs)
+    if (ps != TOPAY_OK) return ps;
+  }
+  DevBatch d = c->db;
+  d.in_paths = c->paths.as<double>();
+  d.in_off = c->path_off.as<long long>();
+  d.in_len = c->path_len.as<int>();
+  d.in_bvel = c->bvel.as<double>();
+  d.in_bacc = c->bacc.as<double>();
+  d.in_scratch = c->scratch.as<double>();
+  d.in_scratch_stride = (3 * c->Pmax + 1 + TOPAY_MAX_N) * ND;
+  d.in_maxN = TOPAY_MAX_N;
+  d.in_stride_n = 10 * TOPAY_MAX_N - 8;
+  int nm[3] = {0, 0, 0}, nl = 0, o2 = 0;
+  for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {
+    d.queue_off[kk] = o2;
+    d.queue_count[kk] = (int)c->cls[kk].size();
+    o2 += d.queue_count[kk];
+    nl += d.queue_count[kk];
+    for (int b : c->cls[kk]) nm[kk] = std::max(nm[kk], c->hN[b]);
+  }
+  {
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
+    d.started = (int*)dp;
+  }
+  c->h_started[0] = 0;
+  c->n_launched = nl;
+  c->done_observed = false;
+
+  bool chained = false;
+  if (ch.alive) {
+    bool ok = memcmp(&ch.dp, &c->dp, sizeof(DevParams)) == 0;
+    for (int k = 0; k < 3 && ok; k++)
+      if (d.queue_count[k] > 0 && !(ch.has[k] && nm[k] <= ch.nm[k])) ok = false;
+    ChainCtl* h = ch.h[ch.set];
+    const int g = ch.gen;
+    if (ok && host_load(&h->state) == g) {
+      // the slot of generation g + 1 was last used by generation g + 1 - SLOTS: that batch has to be complete
+      const int slot = (g + 1) & (TOPAY_CHAIN_SLOTS - 1);
+      const auto t0 = std::chrono::steady_clock::now();
+      // (a context that has moved on to a newer batch has waited for the old one: only an owner still on that
+      // generation can have an unfinished batch in the slot)
+      auto owner_busy = [&]() {
+        topay_ctx* o = ch.owner[slot];
+        return o && o->pending && o->chained_mode && o->chain_set == ch.set && o->chain_gen == ch.owner_gen[slot] && !o->done_observed;
+      };
+      while (owner_busy() && host_load(&h->finished[slot]) < ch.n_of_slot[slot] && host_load(&h->state) >= 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      if (host_load(&h->state) == g) {
+        if (owner_busy() && ch.owner[slot] != c) ch.owner[slot]->done_observed = true;   // complete: seen just above
+        h->finished[slot] = 0;
+        for (int q = 0; q < 4; q++) h->qnext[slot][q] = 0;
+        d.queue_next = &ch.d[ch.set]->qnext[slot][0];
+        ch.n_of_slot[slot] = nl;
+        ch.owner[slot] = c;
+        ch.owner_gen[slot] = g + 1;
+        d.chain = ch.d[ch.set];
+        d.chain_gen = g + 1;
+        d.order = c->db.order;
+        h->desc[slot].d = d;
+        h->desc[slot].maps = (const DevMap*)c->dmaps.p;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        if (host_cas(&h->state, g, g + 1)) {
+          chained = true;
+          ch.gen = g + 1;
+          c->chain_set = ch.set;
+          c->chain_gen = g + 1;
+        } else {
+          ch.owner[slot] = nullptr;   // a workgroup ended the chain first: nobody will read the slot
+        }
+      }
+    }
+    if (!chained) ch.alive = false;
+  }
+  if (!chained) {
+    // a new chain on the other set; oldest-first hand-over from whatever is still running (dispatch gate)
+    topay_ctx* p = g_last_issued;
+    if (c->gate && p && p != c && p->pending && p->device == c->device && p->h_started) {
+      volatile int* cnt = p->h_started;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (*cnt < p->n_launched) {
+        if (batch_done(p)) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+      }
+    }
+    const int s2 = ch.set ^ 1;
+    for (int k = 0; k < 3; k++) HIPCHK(hipStreamSynchronize(ch.st[s2][k]));  // the chain before the previous one: long over
+    ChainCtl* h = ch.h[s2];
+    {
+      // the kernels that last used this set have ended (synchronised above): whatever batch of theirs a context has
+      // not yet waited for is complete; its counter is about to be reused
+      std::lock_guard<std::mutex> lk(g_registry_mutex);
+      for (topay_ctx* q : g_contexts)
+        if (q != c && q->pending && q->chained_mode && q->device == c->device && q->chain_set == s2) q->done_observed = true;
+    }
+    for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++) {
+      h->finished[q] = 0;
+      for (int r = 0; r < 4; r++) h->qnext[q][r] = 0;
+      ch.n_of_slot[q] = 0;
+      ch.owner[q] = nullptr;
+    }
+    d.queue_next = &ch.d[s2]->qnext[0][0];
+    __atomic_store_n(&h->state, 0, __ATOMIC_RELEASE);
+    ch.n_of_slot[0] = nl;
+    ch.owner[0] = c;
+    ch.owner_gen[0] = 0;
+    d.chain = ch.d[s2];
+    d.chain_gen = 0;
+    d.order = c->db.order;
+    int share[topay_ctx::NBUCKET] = {0};
+    compute_shares(c, c->simd_slots, share);
+    HIPCHK(hipEventRecord(ch.start_ev[s2], c->stream));
+    int launches = 0;
+    for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
+      ch.has[k] = d.queue_count[k] > 0;
+      ch.nm[k] = nm[k];
+      if (!ch.has[k]) continue;
+      d.queue_class = k;
+      const size_t lds = solve_lds_bytes(nm[k]);
+      hipStream_t st = ch.st[s2][k];
+      HIPCHK(hipStreamWaitEvent(st, ch.start_ev[s2], 0));
+      if (nm[k] > 21) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_solve3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve3, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+      } else if (nm[k] > 10) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve2, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+      } else {
+        HIPCHK(hipFuncSetAttribute((const void*)k_solve1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve1, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+      }
+      HIPCHK(hipGetLastError());
+      launches++;
+    }
+    c->last_launches = launches;
+    ch.set = s2;
+    ch.alive = true;
+    ch.gen = 0;
+    ch.dp = c->dp;
+    c->chain_set = s2;
+    c->chain_gen = 0;
+  }
+  c->done_observed = false;
+  c->chained_mode = true;
+  c->pending = true;
+  g_last_issued = c;
+  return TOPAY_OK;
+}
+
 extern "C" {
 
 topay_status topay_optimize_async(topay_ctx* c) {
@@ -999,6 +1315,11 @@ topay_status topay_optimize_async(topay_ctx* c) {
     topay_status s0 = topay_synchronize(c);
     if (s0 != TOPAY_OK) return s0;
   }
+  if (c->chain_enabled && c->persistent) {
+    std::lock_guard<std::mutex> lk(g_issue_mutex);
+    return issue_chained(c);
+  }
+  c->chained_mode = false;
   {
     // Dispatch gate.  Batches of different contexts run on different streams; issued at the same time their waves
     // would be dispatched alternately and both would end in the same long tail.  Holding the new batch back until
@@ -1011,7 +1332,7 @@ topay_status topay_optimize_async(topay_ctx* c) {
       volatile int* cnt = p->h_started;
       const auto t0 = std::chrono::steady_clock::now();
       while (*cnt < p->n_launched) {
-        if (hipStreamQuery(p->stream) == hipSuccess) break;  // finished (or never launched anything)
+        if (batch_done(p)) break;  // finished (or never launched anything)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
         std::this_thread::sleep_for(std::chrono::microseconds(100));
       }
@@ -1039,6 +1360,29 @@ topay_status topay_optimize_async(topay_ctx* c) {
 topay_status topay_synchronize(topay_ctx* c) {
   if (!c) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending && c->chained_mode) {
+    // the kernels outlive the batch: completion is the chain's counter of finished candidates
+    ChainHost& ch = g_chain[c->device % 16];
+    int* f = &ch.h[c->chain_set]->finished[c->chain_gen & (TOPAY_CHAIN_SLOTS - 1)];
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!c->done_observed && host_load(f) < c->n_launched) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) { set_err("chained solve did not complete"); return TOPAY_ERR_NO_DEVICE; }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    c->done_observed = true;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // device time of the batch: first start to last end on the device's constant clock
+    std::vector<double> su(c->B), us(c->B);
+    HIPCHK(memcpy_sync(c, su.data(), c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(c, us.data(), c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
+    double t_lo = 1e300, t_hi = 0.0;
+    for (int b = 0; b < c->B; b++)
+      if (c->hN[b] > 0) { t_lo = std::min(t_lo, su[b]); t_hi = std::max(t_hi, su[b] + us[b]); }
+    c->last_ms = t_hi > t_lo ? (t_hi - t_lo) * 1e-3 : 0.0;
+    c->solved = true;
+    c->pending = false;
+    return TOPAY_OK;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->pending) {
     float ms = 0.f;
