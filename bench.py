@@ -69,13 +69,17 @@ def main():
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain", action="store_true",
+                    help="opt-in batch chaining (TOPAY_CHAIN=1): resident workgroups go on with the next published batch instead of "
+                         "exiting; three batches in flight unless --inflight says otherwise; the record gathers of a multi-GPU run are "
+                         "deferred to the end of the timed region (nothing else runs on a device while a chain lives)")
     ap.add_argument("--no-serial", action="store_true", help="skip the strictly serial steps measured beside a pipelined run")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] latency figure (profiling runs)")
     ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
                     help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
                          "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
     ap.add_argument("--hires-size", type=float, default=50.0)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="batches (contexts) in flight per GPU: step i+1 is issued while step i is still solving and its waves take the "
                          "SIMDs step i's tail leaves idle; 1 = strictly serial steps (also measured and reported beside the line)")
     args = ap.parse_args()
@@ -131,6 +135,11 @@ def main():
     B = len(tb.lens)
     # `--inflight` contexts hold the same batch (in a sweep they would hold consecutive batches): step i runs on context
     # i mod inflight, so the tail of one step -- a few long candidates, most SIMDs idle -- overlaps the bulk of the next.
+    if args.chain:
+        os.environ["TOPAY_CHAIN"] = "1"
+    chain = os.environ.get("TOPAY_CHAIN") == "1"
+    if args.inflight is None:
+        args.inflight = 3 if chain else 2
     depth = max(1, args.inflight)
     opts = []
     edt_ms = None
@@ -162,6 +171,7 @@ def main():
         o_.optimize_async()              # persistent solve kernel (optimizeTraj:359-497)
 
     gathers = []
+    deferred = []
     trace = os.environ.get("TOPAY_BENCH_TRACE") == "1"
     tr0 = time.perf_counter()
 
@@ -176,9 +186,12 @@ def main():
             tc = time.perf_counter()
             # the exchange of step i is started here and collected while step i+1's records are being prepared: the RCCL
             # kernel has to find a compute unit on a device whose SIMDs all hold resident solver waves of the next batch
-            gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
-            while len(gathers) > 1:
-                tdist.gather_records_end(gathers.pop(0))
+            if chain:
+                deferred.append(recs)    # gathered after the last step of the run, still inside the timed region
+            else:
+                gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
+                while len(gathers) > 1:
+                    tdist.gather_records_end(gathers.pop(0))
             if trace:
                 print(f"[trace] finish at {1e3 * (ta - tr0):.0f} ms: wait {1e3 * (tb_ - ta):.1f}, records {1e3 * (tc - tb_):.1f}, "
                       f"gather {1e3 * (time.perf_counter() - tc):.1f} ms", file=sys.stderr)
@@ -195,6 +208,8 @@ def main():
             issue(o_)
         for i in range(max(0, nsteps - depth_), nsteps):
             out_.append(finish(opts[i % depth_]))
+        while deferred:                  # chained run: the device is free again, one gather per step
+            gathers.append(tdist.gather_records_begin(deferred.pop(0), max_rows=S, device=dev))
         while gathers:                   # every step's records are on every rank before the step counts as done
             tdist.gather_records_end(gathers.pop(0))
         return out_
@@ -294,7 +309,7 @@ def main():
                          f"scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, tables map 20x20x1.6 m @0.1 m "
                          "regenerated per scenario, both stages + ALM to convergence"),
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
-            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
+            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU" + (", chained batches" if chain else ""),
             "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
             "gate_pass_fraction_of_successes": float(gate[ok].mean()) if ok.any() else 0.0,
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
