@@ -193,6 +193,30 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   }
 }
 
+// The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).
+template <int RMAX, bool SYSTEM_SCOPE>
+__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int init_stride_N, int my_class) {
+  for (int cls = my_class; cls >= 0; cls--) {
+    const int count = B.queue_count[cls], off = B.queue_off[cls];
+    for (;;) {
+      int pos = 0;
+      if (threadIdx.x == 0) {
+#ifndef TOPAY_CPU_EMU
+        // chained batches keep their counters in the pinned control block: system scope
+        pos = SYSTEM_SCOPE ? __hip_atomic_fetch_add(B.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                           : atomicAdd(B.queue_next + cls, 1);
+#else
+        pos = atomicAdd(B.queue_next + cls, 1);
+#endif
+      }
+      pos = __shfl(pos, 0);
+      if (pos >= count) break;
+      solve_one<RMAX>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
+      __syncthreads();
+    }
+  }
+}
+
 // Persistent launch: the grid is one workgroup per SIMD slot (or fewer), and every workgroup takes candidates from the
 // launch's queue -- positions of `order`, longest first -- until it is empty.  The hardware dispatcher places workgroups
 // in order on a fixed round-robin of XCDs / shader engines and stalls on a full one while others have room (about 10 %
@@ -206,28 +230,14 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     return;
   }
   const int my_class = Bt.queue_class;
+  if (!Bt.chain) {   // plain persistent launch: the batch is the kernel argument (scalar loads, no copy)
+    drain_queues<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, my_class);
+    return;
+  }
   DevBatch cur = Bt;
   const DevMap* cmaps = maps;
   for (;;) {
-    for (int cls = my_class; cls >= 0; cls--) {
-      const int count = cur.queue_count[cls], off = cur.queue_off[cls];
-      for (;;) {
-        int pos = 0;
-        if (threadIdx.x == 0) {
-#ifndef TOPAY_CPU_EMU
-          // chained batches keep their counters in the pinned control block: system scope
-          pos = cur.chain ? __hip_atomic_fetch_add(cur.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                          : atomicAdd(cur.queue_next + cls, 1);
-#else
-          pos = atomicAdd(cur.queue_next + cls, 1);
-#endif
-        }
-        pos = __shfl(pos, 0);
-        if (pos >= count) break;
-        solve_one<RMAX>(cur, cmaps, Nmax_lds, init_stride_N, cur.order[off + pos]);
-        __syncthreads();
-      }
-    }
+    drain_queues<RMAX, true>(cur, cmaps, Nmax_lds, init_stride_N, my_class);
     // out of work in this batch: go on with the next one if the host has published it (ChainCtl), else end the chain
     ChainCtl* ch = cur.chain;
     if (!ch) break;
