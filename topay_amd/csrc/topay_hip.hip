@@ -111,10 +111,10 @@ __device__ __noinline__ void init_candidate(const DevBatch& Bt, int b) {
            Bt.x0 + (size_t)b * Bt.in_stride_n);
 }
 
-template <int RMAX>
+template <int RMAX, bool CHAIN>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N, int b) {
   const unsigned long long t_begin = wall_clock64();
-  if (Bt.in_paths) {  // optimizeTraj:146-357 for this candidate (one lane; the result is what the init kernel writes)
+  if (CHAIN && Bt.in_paths) {  // optimizeTraj:146-357 for this candidate (one lane; the result is what the init kernel writes)
     if (threadIdx.x == 0) init_candidate(Bt, b);
     __threadfence();
     __syncthreads();
@@ -181,7 +181,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
     Bt.hw_id[b] = 0;
 #endif
   }
-  if (Bt.chain) {
+  if (CHAIN && Bt.chain) {
     // completion signal of a chained batch: results first (release at system scope), then the count
 #ifndef TOPAY_CPU_EMU
     __threadfence_system();
@@ -211,7 +211,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
       }
       pos = __shfl(pos, 0);
       if (pos >= count) break;
-      solve_one<RMAX>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
+      solve_one<RMAX, SYSTEM_SCOPE>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -223,14 +223,14 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // of the slots stay empty when it has to place 8000 workgroups of unequal length); a resident wave that fetches its
 // next candidate itself leaves no slot idle and starts candidates strictly in queue order.  Which wave solves which
 // candidate is timing-dependent, the result of a candidate is not (nothing is shared between candidates).
-template <int RMAX>
+template <int RMAX, bool CHAIN>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N) {
-  if (!Bt.queue_next) {
-    solve_one<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
+  if (!CHAIN && !Bt.queue_next) {
+    solve_one<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
     return;
   }
   const int my_class = Bt.queue_class;
-  if (!Bt.chain) {   // plain persistent launch: the batch is the kernel argument (scalar loads, no copy)
+  if (!CHAIN) {   // plain persistent launch: the batch is the kernel argument (scalar loads, no copy)
     drain_queues<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, my_class);
     return;
   }
@@ -273,13 +273,25 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 }
 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<1>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<1, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<1, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<2>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<2, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<2, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<3>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<3, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<3, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
@@ -1289,14 +1301,14 @@ static topay_status issue_chained(topay_ctx* c) {
       hipStream_t st = ch.st[s2][k];
       HIPCHK(hipStreamWaitEvent(st, ch.start_ev[s2], 0));
       if (nm[k] > 21) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_solve3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve3, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+        HIPCHK(hipFuncSetAttribute((const void*)k_chain3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chain3, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
       } else if (nm[k] > 10) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_solve2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve2, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+        HIPCHK(hipFuncSetAttribute((const void*)k_chain2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chain2, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
       } else {
-        HIPCHK(hipFuncSetAttribute((const void*)k_solve1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve1, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
+        HIPCHK(hipFuncSetAttribute((const void*)k_chain1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chain1, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
       }
       HIPCHK(hipGetLastError());
       launches++;
