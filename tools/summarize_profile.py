@@ -96,7 +96,7 @@ def main(src, dst, tag):
         cols, rows = q(db, "select kernel_name, count(*), sum(value) from counters_collection where kernel_name like 'k_%' "
                            "group by kernel_name")
         out.append("")
-        out.append(f"## {ctr} (separate --pmc pass; KiB as reported, summed over the dispatches of 3 steps)")
+        out.append(f"## {ctr} (separate --pmc pass with TOPAY_STEAL=0: the pass serialises the launches of a step, and with shared queues the first launch would solve the whole batch alone, out of L2; KiB as reported, summed over the dispatches of 3 steps)")
         out.append("")
         out.append("| kernel | dispatches | sum KiB | per step GB |")
         out.append("|---|---:|---:|---:|")

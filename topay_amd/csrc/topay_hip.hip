@@ -196,7 +196,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).
 template <int RMAX, bool SYSTEM_SCOPE>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int init_stride_N, int my_class) {
-  for (int cls = my_class; cls >= 0; cls--) {
+  for (int cls = my_class; cls >= B.queue_lowest; cls--) {
     const int count = B.queue_count[cls], off = B.queue_off[cls];
     for (;;) {
       int pos = 0;
@@ -473,6 +473,7 @@ struct topay_ctx {
   int n_launched = 0;        // candidates the pending solve launched
   bool gate = true;
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
+  bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
   bool chain_enabled = false;  // TOPAY_CHAIN: resident workgroups go on with the next published batch instead of exiting
   bool chained_mode = false;   // the pending solve signals completion through the chain's counter, not through the stream
   bool done_observed = false;  // ... and somebody has already seen that counter reach n_launched
@@ -655,6 +656,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   }
   {
     { const char* ce = getenv("TOPAY_CHAIN"); c->chain_enabled = ce && ce[0] == '1'; }
+    { const char* se = getenv("TOPAY_STEAL"); c->steal = !(se && se[0] == '0'); }
     const char* pe = getenv("TOPAY_PERSISTENT");
     c->persistent = !(pe && pe[0] == '0');
     hipDeviceProp_t prop;
@@ -1096,6 +1098,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2
       d.order = c->db.order;
       d.queue_next = c->qnext.as<int>();
       d.queue_class = k;
+      d.queue_lowest = c->steal ? 0 : k;
       int o2 = 0;
       for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {   // `order` holds the classes largest first
         d.queue_off[kk] = o2;

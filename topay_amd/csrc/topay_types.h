@@ -113,6 +113,7 @@ struct DevBatch {
   // queue_next == null: one workgroup per position of `order`.
   int* queue_next;
   int queue_count[3], queue_off[3], queue_class;
+  int queue_lowest;   // 0: drain the smaller classes' queues too; = queue_class: own queue only (TOPAY_STEAL=0, profiling)
   // Chained batches initialise a candidate inside the solve (optimizeTraj:146-357 by the workgroup that is about to solve
   // it) instead of by a separate kernel: nothing but resident workgroups can run on a device they occupy.  Null in_paths:
   // the init kernel has done it.
