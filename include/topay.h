@@ -172,7 +172,8 @@ topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len,
                                  const double* boundary_vel, const double* boundary_acc, const int* map_ids);
 
 /* Re-run the init kernel from the resident raw paths (restores x0 so the same batch can be
- * optimised again; used by bench.py so every timed step starts from HBM-resident inputs). */
+ * optimised again; used by bench.py so every timed step starts from HBM-resident inputs).  With batch chaining
+ * (TOPAY_CHAIN=1) the init step runs inside the solve and this call does nothing. */
 topay_status topay_reset(topay_ctx* ctx);
 
 /* == optimizeTraj lines 359-497 for every batch member (stage-1 L-BFGS, stage-2 ALM loop). */
@@ -180,8 +181,10 @@ topay_status topay_optimize(topay_ctx* ctx);
 
 /* The same in two halves, so that a caller can keep several contexts (batches) in flight on one GPU: the tail of one
  * batch -- a few long candidates, most of the device idle -- then overlaps the bulk of the next.  topay_optimize ==
- * topay_optimize_async + topay_synchronize.  Results may be read after topay_synchronize.  (All contexts of a process
- * share one parameter block in constant memory: contexts in flight together must use identical parameters.) */
+ * topay_optimize_async + topay_synchronize.  Results may be read after topay_synchronize.  The asynchronous call may
+ * block until every candidate of the batch issued before it (by any context of the process on this device) has started:
+ * the library hands the device over oldest batch first.  All contexts of a process share one parameter block in constant
+ * memory: a solve whose parameters differ from those of a solve still in flight waits for that one to finish. */
 topay_status topay_optimize_async(topay_ctx* ctx);
 topay_status topay_synchronize(topay_ctx* ctx);
 
