@@ -162,6 +162,7 @@ def main():
         opts.append(o_)
     opt = opts[0]
     n_pieces = opt.n_pieces()
+    n_not_launched = int((n_pieces <= 0).sum())
     setup_s = time.time() - t0
     scen_global = tb.scen.astype(np.int64) + rank * S
     scen_ids = np.array(sorted(set(scen_global.tolist())), dtype=np.int64)
@@ -240,11 +241,11 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tot = torch.tensor([float(B)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(B - n_not_launched)], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_traj = float(tot.item())
     else:
-        total_traj = float(B)
+        total_traj = float(B - n_not_launched)   # only candidates the device actually solved count
 
     # BASELINE configs[1] (one tables scenario x 64 candidates) as a latency figure beside the throughput line: the batch
     # is far too small to fill the device (64 wavefronts), so its time is the longest candidate's.
@@ -310,7 +311,10 @@ def main():
                          "regenerated per scenario, both stages + ALM to convergence"),
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
             "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU" + (", chained batches" if chain else ""),
-            "mean_pieces": float(n_pieces.mean()), "success_fraction": float(ok.mean()),
+            "mean_pieces": float(n_pieces.mean()), "max_pieces": int(n_pieces.max()),
+            "pieces_over_32": int((n_pieces > 32).sum()),
+            # candidates the device did not solve (more pieces than the build supports): none may hide in `value`
+            "n_not_launched": n_not_launched, "success_fraction": float(ok.mean()),
             "gate_pass_fraction_of_successes": float(gate[ok].mean()) if ok.any() else 0.0,
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),

@@ -166,8 +166,10 @@ topay_status topay_get_map(topay_ctx* ctx, int map_id, double* esdf2d, double* e
  *                    (row 0 = v, row 1 = omega, rows 3-9 = joints; col 0 = start, col 1 = end); NULL = zeros
  *   map_ids          map slot per candidate, NULL = all slot 0
  * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace.
- * A candidate whose time allocation needs more than 32 pieces (paths longer than ~45 s) cannot be represented by this
- * build: it is reported as failed (success 0, n_pieces 0) and the rest of the batch is solved normally. */
+ * The reference puts no bound on the number of pieces (moma_traj_opt.cpp:245, 300-321); this build solves up to 64
+ * (a 96 s trajectory at the reference's 1.5 s sample_interval: one piece per lane, six system rows per lane).  A
+ * candidate that needs more is reported as failed (success 0, cost NaN, n_pieces 0) without being launched and the
+ * rest of the batch is solved normally; topay_get_batch's n_pieces lets the caller count such candidates. */
 topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len, const double* init_paths,
                                  const double* boundary_vel, const double* boundary_acc, const int* map_ids);
 

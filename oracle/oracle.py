@@ -117,6 +117,12 @@ class Oracle:
         rho = np.ascontiguousarray(rho, dtype=np.float64)
         self.L.orc_set_alm(self.h, _dp(lam), _dp(rho))
 
+    def alm_state(self):
+        """(lambda0, lambda1, rho0, rho1) as the last optimize() left them (moma_traj_opt.cpp:451-459)."""
+        a = np.zeros(4)
+        self.L.orc_get_alm(self.h, _dp(a))
+        return a
+
     def eval(self, stage, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         g = np.zeros_like(x)

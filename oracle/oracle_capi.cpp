@@ -83,6 +83,10 @@ void orc_set_alm(void* hh, const double lambda[2], const double rho[2]) {
   o.alm_lambda[0] = lambda[0]; o.alm_lambda[1] = lambda[1];
   o.alm_rho[0] = rho[0]; o.alm_rho[1] = rho[1];
 }
+void orc_get_alm(void* hh, double out4[4]) {  // lambda0, lambda1, rho0, rho1 as the last solve left them
+  TrajOpt& o = ((OracleHandle*)hh)->opt;
+  out4[0] = o.alm_lambda[0]; out4[1] = o.alm_lambda[1]; out4[2] = o.alm_rho[0]; out4[3] = o.alm_rho[1];
+}
 // one cost/gradient evaluation (stage 1 or 2) at x — the unit of parity
 double orc_eval(void* hh, int stage, const double* x, double* g) {
   TrajOpt& o = ((OracleHandle*)hh)->opt;

@@ -5,7 +5,7 @@ iteration has not yet amplified rounding differences (capped iterations), see DE
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, set_map
+from conftest import EMU_LIB, serpentine_path, set_map
 from oracle import oracle as orc
 from topay_amd import api
 from topay_amd.harness import workload as wl
@@ -100,6 +100,51 @@ def test_capped_solve_matches_oracle(cuboids_small):
         assert np.allclose(tr["knots_xy"], kn, atol=1e-7)
 
 
+def alm_rounds_case(opt_factory, cs, sel, budget):
+    """Shared by the emulator and the GPU test: three ALM rounds of five stage-2 iterations each (every round ends with
+    LBFGSERR_MAXIMUMITERATION, so the multiplier / penalty update of moma_traj_opt.cpp:451-459 runs between rounds), or,
+    with a small work budget, an exit through the deterministic stand-in for the reference's 1 s clock (403-407).
+    Counters and final (lambda, rho) must equal the oracle's exactly, the iterate to 1e-7."""
+    lib = opt_factory(None).L
+    p = api.default_params(lib)
+    p.s2_lbfgs.max_iterations = 5
+    p.alm_max_outer = 3
+    p.alm_work_budget = budget
+    opt = opt_factory(p)
+    set_map(opt, cs["world"])
+    lens = cs["lens"][sel]
+    paths = np.concatenate([cs["paths"][cs["offs"][i]:cs["offs"][i + 1]] for i in sel])
+    opt.optimizeTraj(lens, paths)
+    st = opt.stats()
+    alm = opt.alm_state()
+    rounds = []
+    for k, b in enumerate(sel):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s2_max_iterations", 5)
+        o.set_param("alm_max_outer", 3)
+        o.set_param("alm_work_budget", budget)
+        o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        ok = o.optimize()
+        so = o.stats()
+        assert list(st[k]) == [so[key] for key in api.STAT_KEYS], (k, list(st[k]), so)
+        assert np.allclose(opt.get_x(k), o.get_x(), rtol=1e-7, atol=1e-8)
+        a = o.alm_state()
+        # rho is a product of exact constants; lambda accumulates rho * final_xy_error of each round (1e-7 like the iterate)
+        assert (alm[k, 2:] == a[2:]).all(), (alm[k], a)
+        assert np.allclose(alm[k, :2], a[:2], rtol=1e-6, atol=1e-9), (alm[k], a)
+        assert abs(opt.traj_cost[k] - o.traj_cost()) <= 1e-7 * abs(o.traj_cost())
+        rounds.append(so["alm_outer"])
+    return rounds
+
+
+def test_alm_rounds_match_oracle(cuboids_small):
+    mk = lambda p: api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    rounds = alm_rounds_case(mk, cuboids_small, [0, 1, 5], 24000)
+    assert rounds == [3, 3, 3]                      # lambda / rho were updated twice and a third round ran with them
+    rounds = alm_rounds_case(mk, cuboids_small, [0, 1], 60)
+    assert max(rounds) < 3                          # the work budget ended the loop, in both implementations alike
+
+
 def _zigzag_path(n_legs, leg=1.3):
     """Synthetic long init path (inside the 20 x 20 m map) whose time allocation needs many pieces."""
     pts = [np.array([-8.5, -8.5])]
@@ -117,23 +162,19 @@ def _zigzag_path(n_legs, leg=1.3):
     return np.array(states)
 
 
-def test_three_rows_per_lane_class_and_too_long_paths(cuboids_small):
-    """N in 22..32 uses three system rows per lane; beyond 32 pieces the candidate is reported as failed."""
+def test_three_rows_per_lane_class(cuboids_small):
+    """N in 22..32 uses three system rows per lane."""
     cs = cuboids_small
     mid = _zigzag_path(17)
-    long_ = _zigzag_path(60, leg=1.35)
     opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
     set_map(opt, cs["world"])
     short = cs["paths"][cs["offs"][0]:cs["offs"][1]]
-    lens = np.array([len(mid), len(short), len(long_)], dtype=np.int32)
-    opt.set_init_traj(lens, np.concatenate([mid, short, long_]))
+    lens = np.array([len(mid), len(short)], dtype=np.int32)
+    opt.set_init_traj(lens, np.concatenate([mid, short]))
     N = opt.n_pieces()
     o = orc.Oracle(cs["map"])
     o.set_init_traj(mid)
     assert N[0] == o.N and 22 <= N[0] <= 32, N
-    o_long = orc.Oracle(cs["map"])
-    o_long.set_init_traj(long_)
-    assert o_long.N > 32 and N[2] == 0
     assert np.allclose(opt.get_x(0), o.get_x(), atol=1e-12)
     x = o.get_x() + 0.03 * np.random.default_rng(5).standard_normal(o.n)
     for stage in (1, 2):
@@ -141,9 +182,44 @@ def test_three_rows_per_lane_class_and_too_long_paths(cuboids_small):
         f, g = o.eval(stage, x)
         fe, ge, _ = opt.eval(stage, 0, x, [0.1, 0.2], [1e4, 1e4])
         assert abs(f - fe) <= 1e-12 * abs(f) and np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+
+
+def test_six_rows_per_lane_class_and_too_long_paths(cuboids_small):
+    """N in 33..64 (the reference has no cap, moma_traj_opt.cpp:245, 300-321) runs in the fourth launch class, six system
+    rows per lane: packed initial guess and per-evaluation parity at N = 33, 48 and 64, three kinds of points.  Beyond 64
+    pieces the candidate is reported as failed without a solve."""
+    cs = cuboids_small
+    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 67.0)]
+    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(opt, cs["world"])
+    opt.set_init_traj(np.array([len(p) for p in paths], dtype=np.int32), np.concatenate(paths))
+    N = opt.n_pieces()
+    assert list(N) == [33, 48, 64, 0]
+    rng = np.random.default_rng(11)
+    for k in range(3):
+        o = orc.Oracle(cs["map"])
+        n = o.set_init_traj(paths[k])
+        Nk = o.N
+        assert Nk == N[k] and np.allclose(opt.get_x(k), o.get_x(), rtol=0, atol=1e-12)
+        for trial in range(3):
+            x = o.get_x().copy()
+            if trial == 1:
+                x += 0.03 * rng.standard_normal(n)
+            if trial == 2:  # rare paths: joint velocity/acceleration limits, mean-time band, folded arm
+                x[:Nk] -= 1.6
+                x[Nk - 1] += 2.5
+                x[3 * Nk - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], Nk - 1)
+            for stage in (1, 2):
+                o.set_alm([0.1, 0.2], [1e4, 3e4])
+                f, g = o.eval(stage, x)
+                fe, ge, _ = opt.eval(stage, k, x, [0.1, 0.2], [1e4, 3e4])
+                assert abs(f - fe) <= 1e-12 * abs(f) and np.abs(g - ge).max() <= 1e-11 * np.abs(g).max(), (Nk, trial, stage)
+    o_long = orc.Oracle(cs["map"])
+    o_long.set_init_traj(paths[3])
+    assert o_long.N == 65
     with pytest.raises(api.TopayError):
-        opt.get_x(2)
-    r = opt.getTraj(2)
+        opt.get_x(3)
+    r = opt.getTraj(3)
     assert r["success"] is False and len(r["durations"]) == 0
 
 

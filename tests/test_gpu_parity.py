@@ -12,7 +12,7 @@ Three layers, from tight to loose (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
-from conftest import EMU_LIB, set_map
+from conftest import EMU_LIB, serpentine_path, set_map
 from oracle import oracle as orc
 from topay_amd import api
 from topay_amd.harness import workload as wl
@@ -145,6 +145,86 @@ def test_capped_solve_matches_oracle(cuboids_small):
         assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["knots_xy"], kn, atol=1e-7)
 
 
+def test_alm_rounds_match_oracle(cuboids_small):
+    """The ALM multiplier / penalty update (moma_traj_opt.cpp:451-459) and the work-budget exit on the HIP path against
+    the oracle: counters and rho exact, lambda and the iterate to 1e-7 (three rounds of five stage-2 iterations)."""
+    from test_emu_parity import alm_rounds_case
+
+    mk = lambda p: api.MomaTrajOptBatch(params=p, device=0)
+    assert alm_rounds_case(mk, cuboids_small, [0, 1, 2, 3, 4, 5], 24000) == [3] * 6
+    assert max(alm_rounds_case(mk, cuboids_small, [0, 1, 2, 3], 60)) < 3
+
+
+def test_more_than_32_pieces(cuboids_small):
+    """N = 33, 48, 64 (fourth launch class, six system rows per lane; the reference has no cap, moma_traj_opt.cpp:245,
+    300-321): packed initial guess, per-evaluation cost / gradient against the oracle at three kinds of points, a capped
+    solve with identical counters, and the same capped solve bit-identical to the CPU lane emulator.  N = 65 is reported
+    failed without a solve."""
+    cs = cuboids_small
+    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 67.0)]
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, cs["world"])
+    opt.set_init_traj(lens, np.concatenate(paths))
+    N = opt.n_pieces()
+    assert list(N) == [33, 48, 64, 0]
+    rng = np.random.default_rng(21)
+    for k in range(3):
+        o = orc.Oracle(cs["map"])
+        n = o.set_init_traj(paths[k])
+        Nk = o.N
+        assert np.allclose(opt.get_x(k), o.get_x(), rtol=0, atol=1e-12)
+        for trial in range(3):
+            x = o.get_x().copy()
+            if trial == 1:
+                x += 0.03 * rng.standard_normal(n)
+            if trial == 2:
+                x[:Nk] -= 1.6
+                x[Nk - 1] += 2.5
+                x[3 * Nk - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], Nk - 1)
+            for stage in (1, 2):
+                lam, rho = [0.1, 0.2], [1e4, 3e4]
+                o.set_alm(lam, rho)
+                f, g = o.eval(stage, x)
+                fg, gg, _ = opt.eval(stage, k, x, lam, rho)
+                assert abs(f - fg) <= 1e-11 * abs(f), (Nk, trial, stage)
+                assert np.abs(g - gg).max() <= 1e-10 * np.abs(g).max(), (Nk, trial, stage)
+    # capped solves: stage 1 in full (not chaotic), eight stage-2 iterations
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 8
+    p.alm_max_outer = 1
+    cap = api.MomaTrajOptBatch(params=p, device=0)
+    set_map(cap, cs["world"])
+    ok = cap.optimizeTraj(lens, np.concatenate(paths))
+    st = cap.stats()
+    assert not ok[3] and np.isnan(cap.traj_cost[3]) and (st[3] == 0).all()
+    for k in range(3):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s2_max_iterations", 8)
+        o.set_param("alm_max_outer", 1)
+        o.set_init_traj(paths[k])
+        o.optimize()
+        so = o.stats()
+        assert list(st[k]) == [so[key] for key in api.STAT_KEYS], (k, list(st[k]), so)
+        assert np.allclose(cap.get_x(k), o.get_x(), rtol=1e-7, atol=1e-8)
+        tr = cap.getTraj(k)
+        d, c, kn = o.get_traj()
+        assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["knots_xy"], kn, atol=1e-7)
+    # N = 33 against the lane emulator, every bit (few iterations: the emulator is slow)
+    p.s1_lbfgs.max_iterations = 5
+    p.s2_lbfgs.max_iterations = 3
+    res = []
+    for lib in (None, EMU_LIB):
+        o2 = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+        set_map(o2, cs["world"])
+        o2.set_init_traj(lens[:1], paths[0])
+        o2.set_trace(64)
+        o2.optimize()
+        res.append((o2.stats(), o2.get_trace(0), o2.get_x(0), o2.getTraj(0)["coeffs"]))
+    g, e = res
+    assert (g[0] == e[0]).all() and (g[1] == e[1]).all() and (g[2] == e[2]).all() and (g[3] == e[3]).all()
+
+
 def test_config2_tables_64_candidates():
     """BASELINE config 2: one 'tables' scenario x 64 candidates.  Properties of the converged batch + statistical
     agreement with the CPU oracle (converged values themselves are not comparable one by one: chaotic iteration)."""
@@ -275,7 +355,7 @@ def test_config3_full_size_properties():
 
 
 def test_eval_parity_every_bucket_multi_map():
-    """Per-evaluation parity HIP vs oracle over every N bucket (rows per lane 1, 2 and 3), three kinds of points
+    """Per-evaluation parity HIP vs oracle over every N bucket (rows per lane 1, 2, 3 and 6), three kinds of points
     (initial guess, random perturbation, rare-path trigger), both stages, every candidate against its own map."""
     tb = wl.TablesBatch(128, 8, base_seed=7000, nthreads=0)
     opt = api.MomaTrajOptBatch(device=0)
@@ -292,7 +372,7 @@ def test_eval_parity_every_bucket_multi_map():
     offs = np.concatenate([[0], np.cumsum(tb.lens)])
     rng = np.random.default_rng(1)
     buckets_seen = 0
-    for lo, hi in ((3, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32)):
+    for lo, hi in ((3, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32), (33, 64)):
         idx = np.nonzero((N >= lo) & (N <= hi))[0]
         if len(idx) == 0:
             continue

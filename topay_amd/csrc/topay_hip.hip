@@ -293,6 +293,13 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
   solve_body<3, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
+// class 4: six system rows per lane (N <= 64)
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<6, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<6, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
@@ -302,6 +309,10 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval2(DevBatch Bt, c
 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval3(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<3>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+}
+
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval4(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<6>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 
 // feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
@@ -404,20 +415,19 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
-#define TOPAY_NBUCKET 3
-// Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3).
-// Each bucket is one launch on its own stream so that the three run concurrently.  All streams have the SAME priority:
+// Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3 / 6).
+// Each bucket is one launch on its own stream so that they run concurrently.  All streams have the SAME priority:
 // mixed priorities made the hardware preempt (context-save) the low-priority waves whenever high-priority work
 // arrived, and twice in ~80 runs one low-priority launch was starved for tens of seconds.  HIP maps the streams of one
 // priority onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues shared by every stream of the process, and
-// streams that share a queue serialise (tools/queue_probe.hip); the library asks for 8 queues at load time (below)
-// when the environment does not say otherwise.  With one wave per SIMD, LDS (<= 20 / 36 / 53 KB per wave) is not
-// what limits residency, so finer buckets would buy nothing.
-static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32};
+// streams that share a queue serialise (tools/queue_probe.hip); the library asks for 16 queues at load time (below)
+// when the environment does not say otherwise.  With one wave per SIMD, LDS (<= 20 / 36 / 53 KB per wave; the rare
+// fourth class up to 107 KB) is not what limits residency, so finer buckets would buy nothing.
+static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32, TOPAY_MAX_N};
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
-// GPU_MAX_HW_QUEUES=8 itself.
+// GPU_MAX_HW_QUEUES=16 itself.
 __attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 // Dispatch gate (topay_optimize_async): the context whose solve was issued last in this process.
 struct topay_ctx;
@@ -433,13 +443,13 @@ struct ChainHost {
   bool inited = false;
   ChainCtl* h[2] = {nullptr, nullptr};   // pinned host memory
   ChainCtl* d[2] = {nullptr, nullptr};   // the same blocks as the device sees them
-  hipStream_t st[2][3] = {{nullptr}};
+  hipStream_t st[2][TOPAY_NBUCKET] = {{nullptr}};
   hipEvent_t start_ev[2] = {nullptr, nullptr};
   int set = 0;
   bool alive = false;
   int gen = 0;                           // latest generation published (or launched) on the current set
-  int nm[3] = {0, 0, 0};                 // LDS sizing (max N) of the running kernels per class
-  bool has[3] = {false, false, false};
+  int nm[TOPAY_NBUCKET] = {0};           // LDS sizing (max N) of the running kernels per class
+  bool has[TOPAY_NBUCKET] = {false};
   DevParams dp;
   int n_of_slot[TOPAY_CHAIN_SLOTS] = {0};
   topay_ctx* owner[TOPAY_CHAIN_SLOTS] = {nullptr};   // context whose batch used the slot last, and that batch's generation
@@ -1068,14 +1078,43 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   }
 }
 
-template <typename KF1, typename KF2, typename KF3, typename... Args>
-static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2, KF3 k3, Args... args) {
+// Kernel of launch class k (rows per lane 1 / 2 / 3 / 6).  The class index selects the template -- also when the
+// diagnostic TOPAY_FORCE_CLASS routes small candidates through a larger class -- and the LDS is sized by the longest
+// candidate actually in the class.
+typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
+typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
+static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve3, k_solve4};
+static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain3, k_chain4};
+static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval3, k_eval4};
+
+// Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most its class can ask
+// for (the launch itself passes the size it needs), not per launch: two host threads launching different contexts
+// would otherwise interleave set(small), set(large), launch(large).
+static std::once_flag g_attr_once[16];
+static hipError_t g_attr_err[16];
+static hipError_t set_kernel_attributes(int device) {
+  std::call_once(g_attr_once[device % 16], [device] {
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
+      const int lds = (int)solve_lds_bytes(kBucketMaxN[k]);
+      e = hipFuncSetAttribute((const void*)kSolveKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kChainKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kEvalKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    g_attr_err[device % 16] = e;
+  });
+  return g_attr_err[device % 16];
+}
+
+template <typename KF, typename... Args>
+static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kernels, Args... args) {
   // One launch per N-bucket, each on its own stream so that the tail of one bucket overlaps the others.
   // Longest jobs first.  The context's main stream waits for all of them (events), so the caller's
   // ev0/ev1 pair on the main stream brackets the whole solve.
   int launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
+  HIPCHK(set_kernel_attributes(c->device));
   int slots = 0;
   if (persistent) {
     if (c->qnext.ensure(sizeof(int) * topay_ctx::NBUCKET) != TOPAY_OK) return TOPAY_ERR_NO_DEVICE;
@@ -1111,16 +1150,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, KF1 k1, KF2 k2
     const size_t lds = solve_lds_bytes(nm);
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
-    if (nm > 21) {
-      HIPCHK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k3, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
-    } else if (nm > 10) {
-      HIPCHK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k2, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
-    } else {
-      HIPCHK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k1, dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
-    }
+    hipLaunchKernelGGL(kernels[k], dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
     HIPCHK(hipGetLastError());
     if (st != c->stream) HIPCHK(hipEventRecord(c->bevent[k], st));
     launches++;
@@ -1155,7 +1185,7 @@ static topay_status chain_init(ChainHost& ch) {
     void* dp = nullptr;
     HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
     ch.d[s_] = (ChainCtl*)dp;
-    for (int k = 0; k < 3; k++) HIPCHK(hipStreamCreateWithFlags(&ch.st[s_][k], hipStreamNonBlocking));
+    for (int k = 0; k < TOPAY_NBUCKET; k++) HIPCHK(hipStreamCreateWithFlags(&ch.st[s_][k], hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ch.start_ev[s_]));
   }
   ch.inited = true;
@@ -1191,7 +1221,7 @@ static topay_status issue_chained(topay_ctx* c) {
   d.in_scratch_stride = (3 * c->Pmax + 1 + TOPAY_MAX_N) * ND;
   d.in_maxN = TOPAY_MAX_N;
   d.in_stride_n = 10 * TOPAY_MAX_N - 8;
-  int nm[3] = {0, 0, 0}, nl = 0, o2 = 0;
+  int nm[TOPAY_NBUCKET] = {0}, nl = 0, o2 = 0;
   for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {
     d.queue_off[kk] = o2;
     d.queue_count[kk] = (int)c->cls[kk].size();
@@ -1211,7 +1241,7 @@ static topay_status issue_chained(topay_ctx* c) {
   bool chained = false;
   if (ch.alive) {
     bool ok = memcmp(&ch.dp, &c->dp, sizeof(DevParams)) == 0;
-    for (int k = 0; k < 3 && ok; k++)
+    for (int k = 0; k < TOPAY_NBUCKET && ok; k++)
       if (d.queue_count[k] > 0 && !(ch.has[k] && nm[k] <= ch.nm[k])) ok = false;
     ChainCtl* h = ch.h[ch.set];
     const int g = ch.gen;
@@ -1268,7 +1298,7 @@ static topay_status issue_chained(topay_ctx* c) {
       }
     }
     const int s2 = ch.set ^ 1;
-    for (int k = 0; k < 3; k++) HIPCHK(hipStreamSynchronize(ch.st[s2][k]));  // the chain before the previous one: long over
+    for (int k = 0; k < TOPAY_NBUCKET; k++) HIPCHK(hipStreamSynchronize(ch.st[s2][k]));  // the chain before the previous one: long over
     ChainCtl* h = ch.h[s2];
     {
       // the kernels that last used this set have ended (synchronised above): whatever batch of theirs a context has
@@ -1293,6 +1323,7 @@ static topay_status issue_chained(topay_ctx* c) {
     d.order = c->db.order;
     int share[topay_ctx::NBUCKET] = {0};
     compute_shares(c, c->simd_slots, share);
+    HIPCHK(set_kernel_attributes(c->device));
     HIPCHK(hipEventRecord(ch.start_ev[s2], c->stream));
     int launches = 0;
     for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
@@ -1303,16 +1334,7 @@ static topay_status issue_chained(topay_ctx* c) {
       const size_t lds = solve_lds_bytes(nm[k]);
       hipStream_t st = ch.st[s2][k];
       HIPCHK(hipStreamWaitEvent(st, ch.start_ev[s2], 0));
-      if (nm[k] > 21) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_chain3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_chain3, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
-      } else if (nm[k] > 10) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_chain2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_chain2, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
-      } else {
-        HIPCHK(hipFuncSetAttribute((const void*)k_chain1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_chain1, dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
-      }
+      hipLaunchKernelGGL(kChainKernels[k], dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
       HIPCHK(hipGetLastError());
       launches++;
     }
@@ -1375,7 +1397,7 @@ topay_status topay_optimize_async(topay_ctx* c) {
   // candidates that were not launched keep success = 0 and cost = NaN
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
-  topay_status s = launch_classes(c, c->persistent, k_solve1, k_solve2, k_solve3);
+  topay_status s = launch_classes(c, c->persistent, kSolveKernels);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   c->pending = true;
@@ -1599,16 +1621,8 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   d.order = tmp.as<int>();
   const size_t lds = solve_lds_bytes(N);
   if ((s = push_params(c)) != TOPAY_OK) return s;
-  if (N <= 10) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_eval1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_eval1, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
-  } else if (N <= 21) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_eval2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_eval2, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
-  } else {
-    HIPCHK(hipFuncSetAttribute((const void*)k_eval3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_eval3, dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
-  }
+  HIPCHK(set_kernel_attributes(c->device));
+  hipLaunchKernelGGL(kEvalKernels[bucket_of(N)], dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   tmp.release();
@@ -1636,7 +1650,7 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   HIPCHK(memcpy_sync(c, c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(memcpy_sync(c, c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  topay_status s = launch_classes(c, false, k_eval1, k_eval2, k_eval3, stage, repeats);
+  topay_status s = launch_classes(c, false, kEvalKernels, stage, repeats);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -6,7 +6,12 @@
 #define TOPAY_SP 25         // samples per piece = 2K+1
 #define TOPAY_EP 13         // even ("full") samples per piece = K+1
 #define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
-#define TOPAY_MAX_N 32      // 6N <= 192 rows = 3 system rows per lane (classes: N<=10 one row, <=21 two, <=32 three)
+// Pieces per trajectory this build solves: 6N <= 384 system rows = 6 rows per lane, one piece per lane (N <= 64 = a 96 s
+// trajectory at the reference's 1.5 s sample_interval).  Launch classes by rows per lane: N <= 10 one row, <= 21 two,
+// <= 32 three, <= 64 six.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer candidates are
+// reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them as n_not_launched).
+#define TOPAY_MAX_N 64
+#define TOPAY_NBUCKET 4
 #define TOPAY_WAVE 64
 
 // Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
@@ -112,7 +117,7 @@ struct DevBatch {
   // queues of the smaller classes (its kernel template and LDS cover them, and results do not depend on the template).
   // queue_next == null: one workgroup per position of `order`.
   int* queue_next;
-  int queue_count[3], queue_off[3], queue_class;
+  int queue_count[TOPAY_NBUCKET], queue_off[TOPAY_NBUCKET], queue_class;
   int queue_lowest;   // 0: drain the smaller classes' queues too; = queue_class: own queue only (TOPAY_STEAL=0, profiling)
   // Chained batches initialise a candidate inside the solve (optimizeTraj:146-357 by the workgroup that is about to solve
   // it) instead of by a separate kernel: nothing but resident workgroups can run on a device they occupy.  Null in_paths:
