@@ -43,11 +43,11 @@ for (i, s, u, th, hw_) in rec:
     s = s - base
     print(f"  batch {i}: first start {s.min()/1e3:.0f}, median start {np.median(s)/1e3:.0f}, last start {s.max()/1e3:.0f}, last end {(s+u).max()/1e3:.0f} (host saw finish at {th*1e3:.0f})")
 Nm = N[m]
-cls = np.where(Nm <= 10, 0, np.where(Nm <= 21, 1, 2))
+cls = np.where(Nm <= 10, 0, np.where(Nm <= 21, 1, np.where(Nm <= 32, 2, np.where(Nm <= 42, 3, 4))))
 for (i, s_, u_, th, hw_) in rec[:6]:
     s0 = s_ - base
     print(f"  batch {i} per class (first start, queue drained = last start, last end) ms:",
-          [(int(s0[cls == k].min() / 1e3), int(s0[cls == k].max() / 1e3), int((s0 + u_)[cls == k].max() / 1e3)) for k in range(3)])
+          [(int(s0[cls == k].min() / 1e3), int(s0[cls == k].max() / 1e3), int((s0 + u_)[cls == k].max() / 1e3)) for k in range(5)])
 T = max((r[1] - base + r[2]).max() for r in rec)
 nb = 40
 edges = np.linspace(0, T, nb + 1)
@@ -77,8 +77,8 @@ bb, ba = B_[:-1][same], B_[1:][same]
 print("  slots seen:", len(np.unique(H)), " gaps >1 ms:", int((gap > 1e3).sum()), " total idle slot-seconds in gaps:", round(gap[gap > 0].sum() / 1e6, 1),
       " of", round(len(np.unique(H)) * T / 1e6, 1))
 big = gap > 1e3
-for k1 in range(3):
-    for k2 in range(3):
+for k1 in range(5):
+    for k2 in range(5):
         q = big & (cb == k1) & (ca == k2)
         if q.any():
             print(f"    class {k1+1} -> class {k2+1}: {int(q.sum())} gaps, mean {gap[q].mean()/1e3:.0f} ms, total {gap[q].sum()/1e6:.1f} slot-s; same batch {int((bb[q]==ba[q]).sum())}")

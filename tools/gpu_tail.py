@@ -25,19 +25,19 @@ print("kernel ms", ms, "B", len(N), "sum wave-seconds", us.sum() / 1e6, "-> idea
 print("N hist", np.bincount(N))
 order = np.argsort(-us)
 print("top 20 by time: (ms, N, evals, iters, ok)")
-for b in order[:20]:
+for b in order[:40]:
     print(f"  {us[b]/1e3:8.1f} {N[b]:3d} {ev[b]:5d} {st[b,1]+st[b,4]:5d} {ok[b]}")
 for q in (50, 90, 99, 99.9):
     print("pct", q, np.percentile(us, q) / 1e3, "ms")
 # time by bucket
-for lo, hi in ((1, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32)):
+for lo, hi in ((1, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32), (33, 42), (43, 64)):
     m = (N >= lo) & (N <= hi)
     if m.any():
         print(f"N {lo}-{hi}: n={m.sum()} wave-s={us[m].sum()/1e6:.2f} max={us[m].max()/1e3:.0f} ms  us/eval={us[m].sum()/ev[m].sum():.1f} mean evals {ev[m].mean():.0f}")
 
 su = opt.start_us()
 print("span of whole solve (first start to last end) ms", (su + us).max() / 1e3)
-for lo, hi in ((1, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32)):
+for lo, hi in ((1, 7), (8, 10), (11, 13), (14, 16), (17, 21), (22, 26), (27, 32), (33, 42), (43, 64)):
     m = (N >= lo) & (N <= hi)
     if m.any():
         print(f"N {lo}-{hi}: first start {su[m].min()/1e3:.0f} ms, last start {su[m].max()/1e3:.0f} ms, last end {(su[m]+us[m]).max()/1e3:.0f} ms")

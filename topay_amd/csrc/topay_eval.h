@@ -508,10 +508,7 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   glb_cdp Vq = c_x + 3 * N - 1;
 
   for (int t = lane; t < 13 * rows; t += 64) band[t] = 0.0;
-  {
-    lds_dp gC0 = C.gC;
-    for (int t = lane; t < 9 * rows; t += 64) { cL[t] = 0.0; gC0[t] = 0.0; }
-  }
+  for (int t = lane; t < 9 * rows; t += 64) cL[t] = 0.0;   // (gC is zeroed when the gradient phase starts)
   if (lane < N) {
     double T1 = expC2(Tau[lane]);  // calTfromTau, moma_traj_opt.h:778-786
     double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
@@ -1299,6 +1296,8 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   if (!gate.needs(f_total)) return f_total;
 
   // =========================== gradient phase ===========================
+  for (int t = lane; t < 9 * rows; t += 64) gC[t] = 0.0;
+  lds_sync();
   // row accumulation from the parked per-sample rows, pass by pass in the order of sweep 1
   for (int pass = 0; pass < npass; pass++) {
 #ifdef TOPAY_STAMPS

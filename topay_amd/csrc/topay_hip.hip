@@ -50,6 +50,7 @@ __global__ void k_init(DevBatch Bt, const double* paths, const long long* path_o
            Bt.x0 + (size_t)b * stride_n);
 }
 
+template <int RMAX>
 __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int init_stride_N) {
   C.lane = threadIdx.x;
   C.N = __builtin_amdgcn_readfirstlane(Bt.N[b]);  // wave-uniform: keep it (and what derives from it) in scalar registers
@@ -83,16 +84,19 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
                                           int init_stride_N, int repeats) {
   const int b = Bt.order[blockIdx.x];
   EvalCtx C;
-  load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
+  load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   C.x = (glb_cdp)(Bt.x + (size_t)b * Bt.nmax);
   C.g = (glb_dp)(Bt.work + (size_t)b * 4 * Bt.nmax);
   C.lam0 = Bt.alm[4 * b]; C.lam1 = Bt.alm[4 * b + 1]; C.rho0 = Bt.alm[4 * b + 2]; C.rho1 = Bt.alm[4 * b + 3];
   __syncthreads();
   double f = 0.0;
+  // (negative repeats: cost only -- the gate then answers "gradient not needed", as for a rejected line-search trial)
+  const bool cost_only = repeats < 0;
+  if (cost_only) repeats = -repeats;
   for (int r = 0; r < repeats; r++) {
     GradGate gate;
-    gate.always = true; gate.has_early = false; gate.finit = 0.0; gate.thr = 0.0; gate.early = 0.0;
+    gate.always = !cost_only; gate.has_early = false; gate.finit = 0.0; gate.thr = -1.0e300; gate.early = 0.0;
     gate.early_ok = false; gate.skip_thr = 0.0;
     if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
     else f = eval_cost_grad<2, RMAX>(C, mp, gate);
@@ -121,7 +125,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   }
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
   // is resident, see topay_optimize_async
-  if (threadIdx.x == 0 && Bt.started) {
+  if (threadIdx.x == 0 && Bt.started && Bt.N[b] <= Bt.gate_maxN) {
 #ifndef TOPAY_CPU_EMU
     __hip_atomic_fetch_add(Bt.started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
@@ -129,7 +133,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx(C, Bt, b, Nmax_lds, init_stride_N);
+  load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8] past costs, then [256] two-loop alpha
   SolveIO S;
@@ -193,23 +197,31 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   }
 }
 
-// The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).
+// The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
+// (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
+// of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
 template <int RMAX, bool SYSTEM_SCOPE>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int init_stride_N, int my_class) {
-  for (int cls = my_class; cls >= B.queue_lowest; cls--) {
-    const int count = B.queue_count[cls], off = B.queue_off[cls];
-    for (;;) {
+  const bool queued = SYSTEM_SCOPE || B.queue_next != nullptr;
+  const int lowest = queued ? B.queue_lowest : my_class;
+  for (int cls = my_class; cls >= lowest; cls--) {
+    const int count = queued ? B.queue_count[cls] : 1, off = queued ? B.queue_off[cls] : (int)blockIdx.x;
+    for (int once = 0;; once++) {
       int pos = 0;
-      if (threadIdx.x == 0) {
+      if (queued) {
+        if (threadIdx.x == 0) {
 #ifndef TOPAY_CPU_EMU
-        // chained batches keep their counters in the pinned control block: system scope
-        pos = SYSTEM_SCOPE ? __hip_atomic_fetch_add(B.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                           : atomicAdd(B.queue_next + cls, 1);
+          // chained batches keep their counters in the pinned control block: system scope
+          pos = SYSTEM_SCOPE ? __hip_atomic_fetch_add(B.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : atomicAdd(B.queue_next + cls, 1);
 #else
-        pos = atomicAdd(B.queue_next + cls, 1);
+          pos = atomicAdd(B.queue_next + cls, 1);
 #endif
+        }
+        pos = __shfl(pos, 0);
+      } else {
+        pos = once;
       }
-      pos = __shfl(pos, 0);
       if (pos >= count) break;
       solve_one<RMAX, SYSTEM_SCOPE>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
       __syncthreads();
@@ -225,10 +237,6 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // candidate is timing-dependent, the result of a candidate is not (nothing is shared between candidates).
 template <int RMAX, bool CHAIN>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N) {
-  if (!CHAIN && !Bt.queue_next) {
-    solve_one<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, Bt.order[blockIdx.x]);
-    return;
-  }
   const int my_class = Bt.queue_class;
   if (!CHAIN) {   // plain persistent launch: the batch is the kernel argument (scalar loads, no copy)
     drain_queues<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, my_class);
@@ -293,11 +301,17 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
   solve_body<3, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
-// class 4: six system rows per lane (N <= 64)
+// classes 4 and 5: four (N <= 42) and six (N <= 64) system rows per lane
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<6, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<4, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<4, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve6(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
+  solve_body<6, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+}
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain6(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
   solve_body<6, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
@@ -312,6 +326,9 @@ __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval3(DevBatch Bt, c
 }
 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval4(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
+  eval_body<4>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
+}
+__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval6(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<6>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
 }
 
@@ -405,6 +422,13 @@ struct DevBuf {
     bytes = 0;
     HIPCHK(hipMalloc(&p, n));
     bytes = n;
+    // debugging aid (TOPAY_POISON=<byte>): fill every fresh allocation, so that a read of memory nobody has written
+    // shows up on every run instead of only when the allocator hands out dirty pages
+    static const int poison = [] { const char* e = getenv("TOPAY_POISON"); return e ? atoi(e) : -1; }();
+    if (poison >= 0) {
+      HIPCHK(hipMemset(p, poison, n));
+      HIPCHK(hipDeviceSynchronize());
+    }
     return TOPAY_OK;
   }
   void release() {
@@ -415,15 +439,16 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
-// Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3 / 6).
+// Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3 / 4 / 6).
 // Each bucket is one launch on its own stream so that they run concurrently.  All streams have the SAME priority:
 // mixed priorities made the hardware preempt (context-save) the low-priority waves whenever high-priority work
 // arrived, and twice in ~80 runs one low-priority launch was starved for tens of seconds.  HIP maps the streams of one
 // priority onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues shared by every stream of the process, and
 // streams that share a queue serialise (tools/queue_probe.hip); the library asks for 16 queues at load time (below)
-// when the environment does not say otherwise.  With one wave per SIMD, LDS (<= 20 / 36 / 53 KB per wave; the rare
-// fourth class up to 107 KB) is not what limits residency, so finer buckets would buy nothing.
-static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32, TOPAY_MAX_N};
+// when the environment does not say otherwise.  With one wave per SIMD, the LDS of the three common classes (<= 20 /
+// 36 / 53 KB per wave) does not limit residency; the two rare classes of long candidates (<= 70 / 107 KB of a CU's
+// 160 KB) do cost their CU a slot or two, which is why they are kept apart from each other.
+static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32, 42, TOPAY_MAX_N};
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
@@ -481,6 +506,7 @@ struct topay_ctx {
   bool pending = false;  // a topay_optimize_async has been issued and not yet waited for
   int* h_started = nullptr;  // pinned host counter the solve kernels bump once per candidate (dispatch gate)
   int n_launched = 0;        // candidates the pending solve launched
+  int n_gate = 0;            // ... of which the dispatch gate waits for (the classes of up to 32 pieces)
   bool gate = true;
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
@@ -656,8 +682,8 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
   HIPCHK(hipEventCreate(&c->bstart));
-  // Three streams per context (the last class runs on the main stream), all non-blocking and never the null stream:
-  // two contexts then use six of the eight hardware queues the library asks for, and no operation of one context
+  // One stream per launch class (the last class runs on the main stream), all non-blocking and never the null stream:
+  // two contexts then use ten of the sixteen hardware queues the library asks for, and no operation of one context
   // waits for another context's solve.
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     if (k == topay_ctx::NBUCKET - 1) c->bstream[k] = c->stream;
@@ -762,8 +788,8 @@ static int bucket_of(int N) {
   if (force >= 2 && force <= topay_ctx::NBUCKET) k0 = std::max(k0, force - 1);
   return k0;
 }
-// + past-cost ring [8] + two-loop alpha ring [256]
-static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256) * sizeof(double); }
+// + past-cost ring [8] + two-loop alpha ring [256] + the solver state parked across an evaluation [48]
+static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256 + 48) * sizeof(double); }
 
 static bool batch_done(topay_ctx* p);
 // what the __constant__ parameter block of each device holds (last push)
@@ -1078,14 +1104,14 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   }
 }
 
-// Kernel of launch class k (rows per lane 1 / 2 / 3 / 6).  The class index selects the template -- also when the
+// Kernel of launch class k (rows per lane 1 / 2 / 3 / 4 / 6).  The class index selects the template -- also when the
 // diagnostic TOPAY_FORCE_CLASS routes small candidates through a larger class -- and the LDS is sized by the longest
 // candidate actually in the class.
 typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
 typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
-static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve3, k_solve4};
-static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain3, k_chain4};
-static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval3, k_eval4};
+static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve3, k_solve4, k_solve6};
+static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain3, k_chain4, k_chain6};
+static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval3, k_eval4, k_eval6};
 
 // Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most its class can ask
 // for (the launch itself passes the size it needs), not per launch: two host threads launching different contexts
@@ -1137,7 +1163,11 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
       d.order = c->db.order;
       d.queue_next = c->qnext.as<int>();
       d.queue_class = k;
-      d.queue_lowest = c->steal ? 0 : k;
+      // A workgroup whose own queue is empty goes on with the queues of the smaller classes -- but the workgroups of
+      // the two classes of long candidates (70 / 107 KB of LDS, a CU has 160 KB for its four SIMDs) only with each
+      // other's: while they are resident their CU cannot fill its other SIMDs, so they should leave as soon as the
+      // long candidates are done and make room for workgroups (of the next batch) that need a quarter of that.
+      d.queue_lowest = c->steal ? (k >= 3 ? 3 : 0) : k;
       int o2 = 0;
       for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {   // `order` holds the classes largest first
         d.queue_off[kk] = o2;
@@ -1236,6 +1266,8 @@ static topay_status issue_chained(topay_ctx* c) {
   }
   c->h_started[0] = 0;
   c->n_launched = nl;
+  c->n_gate = nl;
+  d.gate_maxN = TOPAY_MAX_N;
   c->done_observed = false;
 
   bool chained = false;
@@ -1262,7 +1294,7 @@ static topay_status issue_chained(topay_ctx* c) {
       if (host_load(&h->state) == g) {
         if (owner_busy() && ch.owner[slot] != c) ch.owner[slot]->done_observed = true;   // complete: seen just above
         h->finished[slot] = 0;
-        for (int q = 0; q < 4; q++) h->qnext[slot][q] = 0;
+        for (int q = 0; q < 8; q++) h->qnext[slot][q] = 0;
         d.queue_next = &ch.d[ch.set]->qnext[slot][0];
         ch.n_of_slot[slot] = nl;
         ch.owner[slot] = c;
@@ -1291,7 +1323,7 @@ static topay_status issue_chained(topay_ctx* c) {
     if (c->gate && p && p != c && p->pending && p->device == c->device && p->h_started) {
       volatile int* cnt = p->h_started;
       const auto t0 = std::chrono::steady_clock::now();
-      while (*cnt < p->n_launched) {
+      while (*cnt < p->n_gate) {
         if (batch_done(p)) break;
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
         std::this_thread::sleep_for(std::chrono::microseconds(100));
@@ -1309,7 +1341,7 @@ static topay_status issue_chained(topay_ctx* c) {
     }
     for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++) {
       h->finished[q] = 0;
-      for (int r = 0; r < 4; r++) h->qnext[q][r] = 0;
+      for (int r = 0; r < 8; r++) h->qnext[q][r] = 0;
       ch.n_of_slot[q] = 0;
       ch.owner[q] = nullptr;
     }
@@ -1378,16 +1410,24 @@ topay_status topay_optimize_async(topay_ctx* c) {
     if (c->gate && p && p != c && p->pending && p->device == c->device && p->h_started) {
       volatile int* cnt = p->h_started;
       const auto t0 = std::chrono::steady_clock::now();
-      while (*cnt < p->n_launched) {
+      while (*cnt < p->n_gate) {
         if (batch_done(p)) break;  // finished (or never launched anything)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
         std::this_thread::sleep_for(std::chrono::microseconds(100));
       }
     }
     c->h_started[0] = 0;
-    int nl = 0;
-    for (auto& v : c->cls) nl += (int)v.size();
+    int nl = 0, ng = 0;
+    for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+      nl += (int)c->cls[k].size();
+      if (k <= 2) ng += (int)c->cls[k].size();
+    }
     c->n_launched = nl;
+    // The gate waits for the candidates of the three common classes only: the few workgroups of the two classes of
+    // long candidates need 70 / 107 KB of LDS and may not find a compute unit with that much free until the previous
+    // batch's tail -- holding the whole next batch back for them leaves the rest of the device idle meanwhile.
+    c->n_gate = ng;
+    c->db.gate_maxN = kBucketMaxN[2];
     void* dp = nullptr;
     HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
     c->db.started = (int*)dp;
@@ -1635,7 +1675,7 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
 // Batched hook: evaluate every candidate `repeats` times at its packed initial guess x0 (ALM state = initial).
 topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
-  if ((stage != 1 && stage != 2) || repeats <= 0) return TOPAY_ERR_INVALID_ARG;
+  if ((stage != 1 && stage != 2) || repeats == 0) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   // x <- x0 (strided copy), alm <- init
   std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);

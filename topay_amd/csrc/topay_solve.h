@@ -66,7 +66,7 @@ __device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane)
 
 template <int RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8 + 256] */, int& success_out, double& cost_out) {
+                                                 lds_dp pf /* LDS [8 + 256 + 48] */, int& success_out, double& cost_out) {
   const DevParams& P = g_P;
   const int lane = C.lane, n = __builtin_amdgcn_readfirstlane(C.n);
   constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
@@ -112,8 +112,52 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       const double no_early = past > 0 ? finit + 2.0 * gate.early * (fabs(finit) + 1.0) : gate.thr;
       gate.skip_thr = gate.thr > no_early ? gate.thr : no_early;
     }
+    // The solver's scalar state is parked in LDS across the evaluation (the callees take the whole register file, and
+    // what is live across a call would otherwise be spilled to scratch memory): every lane writes the same values to
+    // the same words and reads them back afterwards.
+    {
+      lds_dp pk = pf + 8 + 256;
+      pk[0] = fx; pk[1] = step; pk[2] = stp; pk[3] = finit; pk[4] = dginit; pk[5] = dgtest; pk[6] = dstest; pk[7] = mu;
+      pk[8] = nu; pk[9] = cost;
+      TOPAY_LDS int* ik = (TOPAY_LDS int*)(pk + 10);
+      ik[0] = stage; ik[1] = alm_iter; ik[2] = st_s1_ret; ik[3] = st_s1_it; ik[4] = st_s1_ev; ik[5] = st_s2_ret; ik[6] = st_s2_it;
+      ik[7] = st_s2_ev; ik[8] = st_sumb; ik[9] = k; ik[10] = end; ik[11] = bound; ik[12] = count; ik[13] = ret; ik[14] = evals;
+      ik[15] = mode; ik[16] = ntrace; ik[17] = (brackt ? 1 : 0) | (touched ? 2 : 0);
+      ik[18] = S.nstride; ik[19] = S.trace_cap; ik[20] = s1_past;
+      TOPAY_LDS unsigned long long* qk = (TOPAY_LDS unsigned long long*)(pk + 21);
+      qk[0] = (unsigned long long)S.x; qk[1] = (unsigned long long)S.g; qk[2] = (unsigned long long)S.xp;
+      qk[3] = (unsigned long long)S.gp; qk[4] = (unsigned long long)S.d; qk[5] = (unsigned long long)S.hist_s;
+      qk[6] = (unsigned long long)S.hist_y; qk[7] = (unsigned long long)S.hist_ys; qk[8] = (unsigned long long)S.hist_al;
+      qk[9] = (unsigned long long)S.stats; qk[10] = (unsigned long long)S.trace; qk[11] = (unsigned long long)mp;
+    }
     if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
     else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+    {
+      // (read back as wave-uniform values: scalar registers, scalar branches, scalar base addresses for the vector loads)
+      lds_cdp pk = pf + 8 + 256;
+      fx = uniform_f64(pk[0]); step = uniform_f64(pk[1]); stp = uniform_f64(pk[2]); finit = uniform_f64(pk[3]);
+      dginit = uniform_f64(pk[4]); dgtest = uniform_f64(pk[5]); dstest = uniform_f64(pk[6]); mu = uniform_f64(pk[7]);
+      nu = uniform_f64(pk[8]); cost = uniform_f64(pk[9]);
+      const TOPAY_LDS int* ik = (const TOPAY_LDS int*)(pk + 10);
+      auto ui = [&](int q) { return __builtin_amdgcn_readfirstlane(ik[q]); };
+      stage = ui(0); alm_iter = ui(1); st_s1_ret = ui(2); st_s1_it = ui(3); st_s1_ev = ui(4); st_s2_ret = ui(5); st_s2_it = ui(6);
+      st_s2_ev = ui(7); st_sumb = ui(8); k = ui(9); end = ui(10); bound = ui(11); count = ui(12); ret = ui(13); evals = ui(14);
+      mode = ui(15); ntrace = ui(16);
+      const int fl = ui(17);
+      brackt = (fl & 1) != 0; touched = (fl & 2) != 0;
+      S.nstride = ui(18); S.trace_cap = ui(19); s1_past = ui(20);
+      const TOPAY_LDS unsigned long long* qk = (const TOPAY_LDS unsigned long long*)(pk + 21);
+      auto up = [&](int q) {
+        const unsigned long long v = qk[q];
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+      };
+      S.x = (glb_dp)up(0); S.g = (glb_dp)up(1); S.xp = (glb_dp)up(2); S.gp = (glb_dp)up(3); S.d = (glb_dp)up(4);
+      S.hist_s = (glb_dp)up(5); S.hist_y = (glb_dp)up(6); S.hist_ys = (glb_dp)up(7); S.hist_al = (glb_dp)up(8);
+      S.stats = (glb_ip)up(9); S.trace = (glb_dp)up(10); mp = (const TOPAY_GLB DevMap*)up(11);
+      f = uniform_f64(f);
+    }
     evals++;
 #ifndef TOPAY_STAMPS
     if (S.trace && lane == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;

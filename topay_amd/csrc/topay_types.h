@@ -8,10 +8,10 @@
 #define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
 // Pieces per trajectory this build solves: 6N <= 384 system rows = 6 rows per lane, one piece per lane (N <= 64 = a 96 s
 // trajectory at the reference's 1.5 s sample_interval).  Launch classes by rows per lane: N <= 10 one row, <= 21 two,
-// <= 32 three, <= 64 six.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer candidates are
+// <= 32 three, <= 42 four, <= 64 six.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer candidates are
 // reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them as n_not_launched).
 #define TOPAY_MAX_N 64
-#define TOPAY_NBUCKET 4
+#define TOPAY_NBUCKET 5
 #define TOPAY_WAVE 64
 
 // Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
@@ -134,6 +134,7 @@ struct DevBatch {
   ChainCtl* chain;
   int chain_gen;
   int* started;       // one counter in pinned host memory: candidates of this launch that have begun (dispatch gate; may be null)
+  int gate_maxN;      // ... counting only candidates with at most this many pieces (the common classes, see topay_optimize_async)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
   double* elapsed_us; // [B] wall time of the solve of this trajectory (constant 100 MHz counter)
   const int* order;   // [B] block -> trajectory map
@@ -161,6 +162,6 @@ struct ChainCtl {
   int state;
   int pad[3];
   int finished[TOPAY_CHAIN_SLOTS];
-  int qnext[TOPAY_CHAIN_SLOTS][4];   // work-queue counters of the batch in slot g & 3 (reset by the host without touching the device)
+  int qnext[TOPAY_CHAIN_SLOTS][8];   // work-queue counters of the batch in slot g & 3 (reset by the host without touching the device)
   ChainDesc desc[TOPAY_CHAIN_SLOTS];
 };
