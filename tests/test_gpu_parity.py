@@ -603,3 +603,57 @@ def test_chained_batches_give_the_serial_results(monkeypatch):
     for o in ctxs + [other]:
         o.close()
     tb.close()
+
+
+@pytest.mark.gpu
+def test_chain_slot_reuse_with_many_contexts_in_flight(monkeypatch):
+    """The chain's control block has four descriptor slots; a slot is reused for generation g + 4 only after every
+    workgroup has LEFT generation g (ChainCtl::departed), not merely after its candidates have finished.  Six contexts
+    with tiny batches keep the publisher as far ahead of the slowest workgroup as it can get: forty batches, six deep,
+    every one must equal the serial result, and nothing may be solved twice or dropped."""
+    tb = wl.TablesBatch(6, 8, base_seed=2718, nthreads=8)
+    per = 8
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 20
+    p.alm_max_outer = 2
+
+    def make(k):
+        sel = slice(k * per, (k + 1) * per)
+        o = api.MomaTrajOptBatch(params=p, device=0)
+        for s_ in sorted(set(tb.scen[sel].tolist())):
+            set_map(o, tb.world(s_), map_id=slot[s_])
+        o.set_init_traj(tb.lens[sel], tb.paths[offs[k * per]:offs[(k + 1) * per]],
+                        map_ids=np.array([slot[s_] for s_ in tb.scen[sel]], dtype=np.int32))
+        return o
+
+    def result(o):
+        return o.finish().copy(), o.traj_cost.copy(), o.stats().copy()
+
+    monkeypatch.delenv("TOPAY_CHAIN", raising=False)
+    want = []
+    for k in range(6):
+        o = make(k)
+        o.optimize_async()
+        want.append(result(o))
+        o.close()
+    monkeypatch.setenv("TOPAY_CHAIN", "1")
+    ctxs = [make(k) for k in range(6)]
+    got = []
+    for i in range(40):
+        k = i % 6
+        if i >= 6:
+            got.append((k, result(ctxs[k])))
+        ctxs[k].reset()
+        ctxs[k].optimize_async()
+    for i in range(34, 40):
+        got.append((i % 6, result(ctxs[i % 6])))
+    assert len(got) == 40
+    for k, g in got:
+        w = want[k]
+        assert (g[0] == w[0]).all() and (g[2] == w[2]).all()
+        assert ((g[1] == w[1]) | (np.isnan(g[1]) & np.isnan(w[1]))).all()
+    for o in ctxs:
+        o.close()
+    tb.close()

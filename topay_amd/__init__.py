@@ -1,7 +1,7 @@
 """topay_amd: MI355X-native batched replacement of TopAY's (s, theta) trajectory NLP.
 
-Importing the package asks the HIP runtime for 8 hardware queues per priority level unless the environment already says
-otherwise: the solver launches its three N-buckets on separate streams, and HIP streams that land on the same hardware
+Importing the package asks the HIP runtime for 16 hardware queues per priority level unless the environment already says
+otherwise: the solver launches its five N-buckets on separate streams, and HIP streams that land on the same hardware
 queue (default pool: 4, shared with every other stream of the process) run one after the other.  The runtime reads the
 variable once, at its first call, so this has to happen before anything initialises HIP in the process.
 """

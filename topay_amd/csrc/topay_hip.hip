@@ -269,6 +269,14 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
     // newest published generation, whether the chain is still open (st >= 0) or ended (st = -2 - newest): a workgroup
     // that lags behind still has to serve every generation that was published before the chain ended
     const int newest = st >= 0 ? st : -2 - st;
+    // this workgroup has left generation gen: its slot of the control block may be reused once all have (ChainCtl)
+    if (threadIdx.x == 0) {
+#ifndef TOPAY_CPU_EMU
+      __hip_atomic_fetch_add(&ch->departed[gen & (TOPAY_CHAIN_SLOTS - 1)], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+      ch->departed[gen & (TOPAY_CHAIN_SLOTS - 1)] += 1;
+#endif
+    }
     if (newest <= gen) break;
 #ifndef TOPAY_CPU_EMU
     __threadfence_system();
@@ -476,6 +484,7 @@ struct ChainHost {
   int nm[TOPAY_NBUCKET] = {0};           // LDS sizing (max N) of the running kernels per class
   bool has[TOPAY_NBUCKET] = {false};
   DevParams dp;
+  int nwg = 0;                           // workgroups of the running chain (all classes)
   int n_of_slot[TOPAY_CHAIN_SLOTS] = {0};
   topay_ctx* owner[TOPAY_CHAIN_SLOTS] = {nullptr};   // context whose batch used the slot last, and that batch's generation
   int owner_gen[TOPAY_CHAIN_SLOTS] = {0};
@@ -757,6 +766,7 @@ void topay_destroy(topay_ctx* c) {
 topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* desc, const double* esdf2d, const double* esdf3d) {
   if (!c || !desc || !esdf2d || !esdf3d || map_id < 0 || map_id >= TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   const size_t n2 = (size_t)desc->dims[0] * desc->dims[1], n3 = n2 * desc->dims[2];
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
   topay_status s;
@@ -840,6 +850,7 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
   if (!c || !desc || !occ2d || !occ3d || n_maps <= 0 || first_map_id < 0 || first_map_id + n_maps > TOPAY_MAX_MAPS)
     return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   const int nx = desc->dims[0], ny = desc->dims[1], nz = desc->dims[2];
   const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, M = (size_t)n_maps;
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
@@ -926,6 +937,10 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->last_edt_ms = ms;
+  // the construction's workspace (occupancy, two intermediate volumes, the envelope stacks, the staged results: about
+  // five times the maps themselves) is not needed once the fields sit in their map slots
+  DevBuf* ws[] = {&c->edt_occ, &c->edt_tmp1, &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3};
+  for (DevBuf* b : ws) b->release();
   return TOPAY_OK;
 }
 
@@ -950,6 +965,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
                                  const double* boundary_vel, const double* boundary_acc, const int* map_ids) {
   if (!c || batch <= 0 || !path_len || !init_paths) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   c->have_traj = false;
   c->solved = false;
   std::vector<long long> off(batch + 1, 0);
@@ -1076,6 +1092,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
 topay_status topay_reset(topay_ctx* c) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   c->solved = false;
   if (c->chain_enabled && c->persistent) return TOPAY_OK;   // chained batches initialise inside the solve (DevBatch::in_paths)
   return run_init(c);
@@ -1278,22 +1295,29 @@ static topay_status issue_chained(topay_ctx* c) {
     ChainCtl* h = ch.h[ch.set];
     const int g = ch.gen;
     if (ok && host_load(&h->state) == g) {
-      // the slot of generation g + 1 was last used by generation g + 1 - SLOTS: that batch has to be complete
+      // the slot of generation g + 1 was last used by generation g + 1 - SLOTS: every workgroup of the chain has to
+      // have left that generation (which also means its batch is complete)
       const int slot = (g + 1) & (TOPAY_CHAIN_SLOTS - 1);
       const auto t0 = std::chrono::steady_clock::now();
-      // (a context that has moved on to a newer batch has waited for the old one: only an owner still on that
-      // generation can have an unfinished batch in the slot)
       auto owner_busy = [&]() {
         topay_ctx* o = ch.owner[slot];
         return o && o->pending && o->chained_mode && o->chain_set == ch.set && o->chain_gen == ch.owner_gen[slot] && !o->done_observed;
       };
-      while (owner_busy() && host_load(&h->finished[slot]) < ch.n_of_slot[slot] && host_load(&h->state) >= 0) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) break;
+      const bool slot_used = g + 1 >= TOPAY_CHAIN_SLOTS;   // generation g + 1 - SLOTS exists in this chain
+      bool timed_out = false;
+      while (slot_used && host_load(&h->departed[slot]) < ch.nwg && host_load(&h->state) >= 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { timed_out = true; break; }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      if (timed_out) {
+        // never publish into a slot that may still be in use: report, and let the caller decide (the chain stays as it is)
+        set_err("chained solve: workgroups did not leave an old generation within 300 s");
+        return TOPAY_ERR_NO_DEVICE;
       }
       if (host_load(&h->state) == g) {
         if (owner_busy() && ch.owner[slot] != c) ch.owner[slot]->done_observed = true;   // complete: seen just above
         h->finished[slot] = 0;
+        h->departed[slot] = 0;
         for (int q = 0; q < 8; q++) h->qnext[slot][q] = 0;
         d.queue_next = &ch.d[ch.set]->qnext[slot][0];
         ch.n_of_slot[slot] = nl;
@@ -1341,6 +1365,7 @@ static topay_status issue_chained(topay_ctx* c) {
     }
     for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++) {
       h->finished[q] = 0;
+      h->departed[q] = 0;
       for (int r = 0; r < 8; r++) h->qnext[q][r] = 0;
       ch.n_of_slot[q] = 0;
       ch.owner[q] = nullptr;
@@ -1371,6 +1396,9 @@ static topay_status issue_chained(topay_ctx* c) {
       launches++;
     }
     c->last_launches = launches;
+    ch.nwg = 0;
+    for (int k = 0; k < topay_ctx::NBUCKET; k++)
+      if (ch.has[k]) ch.nwg += share[k];
     ch.set = s2;
     ch.alive = true;
     ch.gen = 0;
@@ -1646,6 +1674,7 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B || (stage != 1 && stage != 2) || !x) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   const int N = c->hN[i], nn = 10 * N - 8;
   if (N == 0) return TOPAY_ERR_TOO_MANY_PIECES;
   HIPCHK(memcpy_sync(c, c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
@@ -1677,6 +1706,7 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if ((stage != 1 && stage != 2) || repeats == 0) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   // x <- x0 (strided copy), alm <- init
   std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);
   HIPCHK(memcpy_sync(c, x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));

@@ -151,8 +151,11 @@ struct DevBatch {
 //                    chain is over; every workgroup still serves the generations up to g, then exits; the host launches
 //                    afresh.  (-1: no chain has used the block yet.)
 // finished[g & 3] counts the candidates of generation g whose results are in memory (release at system scope before the
-// increment): the host's completion signal, since the kernels outlive the batch.  A slot is reused for generation g + 4
-// only after generation g is complete.
+// increment): the host's completion signal, since the kernels outlive the batch.  departed[g & 3] counts the workgroups
+// that have LEFT generation g (moved on to g + 1, or exited): from then on they touch neither its descriptor nor its
+// queue counters nor its completion counter.  A slot is reused for generation g + 4 only after every workgroup of the
+// chain has left generation g -- candidates finishing is not enough: a workgroup that has just finished its last
+// candidate of g still issues the fetch-adds that tell it the queues are empty, and reads the next descriptor.
 #define TOPAY_CHAIN_SLOTS 4
 struct ChainDesc {
   DevBatch d;
@@ -162,6 +165,7 @@ struct ChainCtl {
   int state;
   int pad[3];
   int finished[TOPAY_CHAIN_SLOTS];
+  int departed[TOPAY_CHAIN_SLOTS];
   int qnext[TOPAY_CHAIN_SLOTS][8];   // work-queue counters of the batch in slot g & 3 (reset by the host without touching the device)
   ChainDesc desc[TOPAY_CHAIN_SLOTS];
 };
