@@ -142,6 +142,7 @@ def main():
         args.inflight = 3 if chain else 2
     depth = max(1, args.inflight)
     opts = []
+    map_ids_of = {}
     edt_ms = None
     for _ in range(depth):
         o_ = api.MomaTrajOptBatch(device=local_rank)
@@ -158,7 +159,8 @@ def main():
                                 np.stack([w.occ3d for w in worlds]))
             edt_ms = o_.get_map(0)[2]
         map_ids = tb_map_of if hires else np.array([slot[s] for s in tb.scen], dtype=np.int32)
-        o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)   # raw init paths + maps now resident in HBM
+        o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)   # (sizes the workspace; every timed step uploads the paths again)
+        map_ids_of[id(o_)] = map_ids
         opts.append(o_)
     opt = opts[0]
     n_pieces = opt.n_pieces()
@@ -168,22 +170,36 @@ def main():
     scen_ids = np.array(sorted(set(scen_global.tolist())), dtype=np.int64)
 
     def issue(o_):
-        o_.reset()                       # init kernel from the resident raw paths (optimizeTraj:146-357)
-        o_.optimize_async()              # persistent solve kernel (optimizeTraj:359-497)
+        # optimizeTraj:146-357: host-to-device copy of the raw init paths + the init kernel, then the persistent solve
+        # kernels (optimizeTraj:359-497).  The maps stay resident (the reference builds its map before optimizeTraj).
+        if chain:
+            o_.reset()                   # chained batches run the init step inside the solve, from the resident paths
+        else:
+            o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids_of[id(o_)])
+        o_.optimize_async()
 
     gathers = []
     deferred = []
     trace = os.environ.get("TOPAY_BENCH_TRACE") == "1"
     tr0 = time.perf_counter()
 
+    winners = {}
+
     def finish(o_):
         ta = time.perf_counter()
-        ok = o_.finish()                 # waits for this context's stream
+        ok = o_.finish()                 # waits for this context's stream; success flags and costs come back
         ms, _ = o_.last_kernel_ms()
+        # What the planner does with a solved scenario (planner.cpp:878-885, 999-1016): a candidate counts when
+        # optimizeTraj succeeded AND printConstraintsSituations passes; of those the shortest one is kept, and that
+        # trajectory is what leaves the device (coefficients, durations, knots of the per-scenario winners).
+        feas = o_.check_feasible()
+        dur = o_.total_durations()
+        recs, best = tdist.scenario_records(scen_ids, scen_global, (ok & feas).astype(np.int32), o_.traj_cost, n_pieces, dur,
+                                            return_winners=True)
+        winners["last"] = o_.getTrajs(best, n_pieces)
+        winners["n"] = len(best)
         tb_ = time.perf_counter()
         if distributed:                  # the one exchange of the path: per-scenario result records over RCCL
-            dur = o_.total_durations()   # the planner keeps the shortest successful candidate of a scenario
-            recs = tdist.scenario_records(scen_ids, scen_global, ok.astype(np.int32), o_.traj_cost, n_pieces, dur)
             tc = time.perf_counter()
             # the exchange of step i is started here and collected while step i+1's records are being prepared: the RCCL
             # kernel has to find a compute unit on a device whose SIMDs all hold resident solver waves of the next batch
@@ -264,7 +280,7 @@ def main():
         o1.close()
         w1.close()
     stats = opt.stats()
-    gate = opt.check_feasible()          # printConstraintsSituations over the batch (untimed; a few milliseconds)
+    gate = opt.check_feasible()          # printConstraintsSituations over the batch (also part of every timed step)
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
     # overlapping, those spans overlap too, so the average wall time per step is used instead (never smaller than the
@@ -320,6 +336,12 @@ def main():
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
             "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),
             "p99_evals_per_traj": float(np.percentile(stats[:, 2] + stats[:, 5], 99)),
+            "timed_region": "per step: host-to-device copy of the raw init paths + init kernel + persistent solve kernels + "
+                            "feasibility gate kernel + device-to-host copy of flags, costs, durations and of the per-scenario "
+                            "winners' trajectories (+ the RCCL record gather when N > 1); maps resident",
+            "h2d_bytes_per_step": int(tb.paths.nbytes + tb.lens.nbytes + 4 * B),
+            "winners_per_step": int(winners.get("n", 0)),
+            "d2h_winner_bytes_per_step": int(sum(v.nbytes for v in winners["last"].values())) if "last" in winners else 0,
             "setup_seconds_untimed": setup_s,
             "esdf_build_ms_gpu_untimed": edt_ms,
             "config1_latency": cfg1,
@@ -358,12 +380,20 @@ def main():
             views.append(orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d))
         mid = np.array([mslot[s_] for s_ in tb.scen[:nsamp]], dtype=np.int32)
         r = orc.optimize_batch_maps(views, mid, tb.lens[:nsamp], tb.paths[:offs[nsamp]], nthreads=cores)
+        # BASELINE configs[0] (single start/goal, one candidate at a time, CPU L-BFGS): the same oracle on ONE thread over
+        # the first candidates of the batch -- the per-candidate latency of the reference's own execution model
+        n1 = min(64, nsamp)
+        r1 = orc.optimize_batch_maps(views, mid[:n1], tb.lens[:n1], tb.paths[:offs[n1]], nthreads=1)
         out["cpu_baseline"] = {
             "value": nsamp / r["seconds"], "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"first {nsamp} trajectories ({len(used)} scenarios) of the same batch, CPU oracle (C++ port of the "
                       f"reference path, oracle/), {cores} worker threads (= usable CPUs: affinity capped by the cgroup quota; the box "
                       f"has {os.cpu_count()} hardware threads), {r['seconds']:.1f} s wall, "
-                      f"{r['seconds_each'].sum():.1f} thread-seconds, success {r['success'].mean():.3f}",
+                      f"{r['seconds_each'].sum():.1f} thread-seconds, success {r['success'].mean():.3f}, "
+                      f"{int((r['n_pieces'] > 32).sum())} of them with more than 32 pieces (all solved, as on the device)",
+            "single_thread": {"value": n1 / r1["seconds"], "unit": "trajectories/s", "cores": 1,
+                              "sample": f"BASELINE configs[0]: first {n1} trajectories one after the other on one thread, "
+                                        f"{r1['seconds']:.1f} s, mean {1e3 * r1['seconds'] / n1:.0f} ms per candidate"},
         }
     if rank == 0:
         print(json.dumps(out))

@@ -199,6 +199,25 @@ topay_status topay_get_batch(topay_ctx* ctx, int* success, double* cost, int* n_
 topay_status topay_get_result(topay_ctx* ctx, int i, int* success, double* cost, int* n_pieces, double* durations,
                               double* coeffs, double* knots_xy);
 
+/* getTraj() for a selection of candidates in ONE call and one device-to-host copy -- what a planner does with the
+ * winners it has picked from topay_get_batch / topay_check_feasible / topay_get_total_durations (planner.cpp:999-1016:
+ * the shortest feasible candidate of a scenario is the one that gets published).  Results are packed by pieces:
+ *   idx[n]              candidate indices (a candidate that was never launched contributes zero pieces)
+ *   piece_off[n + 1]    OUT: candidate k owns pieces [piece_off[k], piece_off[k+1]) of durations / coeffs
+ *   durations[pieces]   coeffs[pieces][9][6] highest order first (minco.hpp:908-921)
+ *   knots_xy            candidate k's N_k + 1 piece end points start at knots_xy[2 * (piece_off[k] + k)]
+ *   cap_pieces          capacity of the output arrays in pieces; TOPAY_ERR_INVALID_ARG when the selection needs more */
+topay_status topay_get_results(topay_ctx* ctx, int n, const int* idx, int cap_pieces, int* piece_off, double* durations,
+                               double* coeffs, double* knots_xy);
+
+/* Candidate i in the layout of src/planner/msg/PolyTraj.msg (uint8 order; std_msgs/Float32MultiArray[] coeff;
+ * float32[] durations; int8[] directions -- the reference defines the message but never fills it, so the field
+ * meanings are the obvious ones): *order = 5; coeff[N][9][6] = getTraj()'s coefficients as float32, one 9 x 6 array per
+ * piece, highest order first; durations[N]; directions[N] = sign of the arc-length rate at the middle of the piece
+ * (+1 forward, -1 reverse).  Capacity cap_pieces; *n_pieces receives N. */
+topay_status topay_get_polytraj_msg(topay_ctx* ctx, int i, int cap_pieces, unsigned char* order, float* coeff,
+                                    float* durations, signed char* directions, int* n_pieces);
+
 /* Per-candidate solver counters, 8 ints each:
  * {stage1_ret, stage1_iters, stage1_evals, stage2_last_ret, stage2_iters, stage2_evals, alm_outer, sum_bound}
  * sum_bound = sum over stage-2 iterations of the two-loop history length (roofline accounting). */

@@ -157,6 +157,10 @@ class Oracle:
     def optimize(self):
         return bool(self.L.orc_optimize(self.h))
 
+    def optimize_warm(self):
+        """Stage-2 ALM loop only, from the x of set_x() and the (lambda, rho) of set_alm()."""
+        return bool(self.L.orc_optimize_warm(self.h))
+
     def optimize_trace(self, cap=100000):
         tr = np.zeros(cap)
         ok = C.c_int(0)

@@ -123,6 +123,8 @@ void orc_get_coeffs(void* hh, double* c, double* T) {
 }
 
 int orc_optimize(void* hh) { return ((OracleHandle*)hh)->opt.optimize() ? 1 : 0; }
+// stage-2 ALM loop only, from the current x and (lambda, rho) (orc_set_x / orc_set_alm)
+int orc_optimize_warm(void* hh) { return ((OracleHandle*)hh)->opt.optimize(true) ? 1 : 0; }
 // optimize with a trace of f at every evaluation; returns number of evaluations recorded (<= cap)
 int orc_optimize_trace(void* hh, double* trace, int cap, int* success) {
   TrajOpt& o = ((OracleHandle*)hh)->opt;

@@ -98,6 +98,17 @@ def test_capped_solve_matches_oracle(cuboids_small):
         d, c, kn = o.get_traj()
         assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["coeffs"], c, rtol=1e-6, atol=1e-7)
         assert np.allclose(tr["knots_xy"], kn, atol=1e-7)
+    # the batched getter (the planner's winners in one call) and the PolyTraj.msg layout return the same numbers
+    pick = [2, 0]
+    pk = opt.getTrajs(pick)
+    for j, k in enumerate(pick):
+        tr = opt.getTraj(k)
+        a, b = pk["piece_off"][j], pk["piece_off"][j + 1]
+        assert (pk["durations"][a:b] == tr["durations"]).all() and (pk["coeffs"][a:b] == tr["coeffs"]).all()
+        assert (pk["knots_xy"][a + j:b + j + 1] == tr["knots_xy"]).all()
+        order, cf, du, dirs = opt.polytraj_msg(k)
+        assert order == 5 and (cf == tr["coeffs"].astype(np.float32)).all() and (du == tr["durations"].astype(np.float32)).all()
+        assert set(dirs.tolist()) <= {-1, 1} and len(dirs) == len(du)
 
 
 def alm_rounds_case(opt_factory, cs, sel, budget):

@@ -249,7 +249,36 @@ def test_config2_tables_64_candidates():
     assert (st[:, :3] == r["stats"][:, :3]).mean() > 0.95
     assert abs(ok.mean() - r["success"].mean()) <= 0.1
     both = ok & (r["success"] == 1)
-    assert abs(np.median(cost[both]) / np.median(r["cost"][both]) - 1.0) < 0.05
+    # cost distribution of the converged candidates: quartiles, not only the median
+    for q in (25, 50, 75):
+        assert abs(np.percentile(cost[both], q) / np.percentile(r["cost"][both], q) - 1.0) < 0.05, q
+    # Converged values cannot be compared one by one (chaotic iteration), and the reference's stop
+    # test (three past costs within 1e-4) also fires on plateaus: restarted at its own result, the reference algorithm
+    # itself moves on by more than 1e-3 in a quarter of the cases (tools/restart_experiment.py).  What can be asserted
+    # is that the device's results are converged IN THE REFERENCE ALGORITHM'S OWN SENSE as often as the reference's:
+    # continue every successful candidate with the oracle's stage-2 loop from the returned x and final (lambda, rho),
+    # and count how often it stops within five iterations having lowered the cost by less than 1e-3 relative.
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    alm = opt.alm_state()
+
+    def settles(path, x, lam_rho, c0):
+        o = orc.Oracle(m)
+        o.set_init_traj(path)
+        o.set_x(x)
+        o.set_alm(lam_rho[:2], lam_rho[2:])
+        o.set_param("alm_max_outer", 1)
+        o.optimize_warm()
+        return o.stats()["stage2_iters"] <= 5 and abs(o.traj_cost() - c0) <= 1e-3 * abs(c0)
+
+    dev, ref = [], []
+    for b in np.nonzero(both)[0]:
+        path = paths[offs[b]:offs[b + 1]]
+        dev.append(settles(path, opt.get_x(int(b)), alm[b], cost[b]))
+        o = orc.Oracle(m)
+        o.set_init_traj(path)
+        o.optimize()
+        ref.append(settles(path, o.get_x(), o.alm_state(), o.traj_cost()))
+    assert np.mean(dev) >= np.mean(ref) - 0.15 and np.mean(dev) > 0.4, (np.mean(dev), np.mean(ref))
 
 
 def test_large_batch_properties_and_multi_map():

@@ -86,6 +86,9 @@ def load(path=None):
     L.topay_synchronize.argtypes = [C.c_void_p]
     L.topay_get_batch.argtypes = [C.c_void_p, c_ip, c_dp, c_ip]
     L.topay_get_result.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, c_dp, c_dp, c_dp]
+    L.topay_get_results.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int, c_ip, c_dp, c_dp, c_dp]
+    L.topay_get_polytraj_msg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_int8), c_ip]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
     L.topay_whole_body_collision.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_ip]
@@ -230,6 +233,33 @@ class MomaTrajOptBatch:
         _chk(self.L, self.L.topay_get_result(self.h, i, C.byref(succ), C.byref(cost), None, _dp(dur), _dp(coef), _dp(knots)))
         return dict(success=bool(succ.value), cost=cost.value, durations=dur, coeffs=coef.reshape(N, 9, 6),
                     knots_xy=knots.reshape(N + 1, 2))
+
+    def getTrajs(self, idx, n_pieces=None):
+        """getTraj() of a selection of candidates in one call / one copy (the planner's winners): dict of packed arrays
+        piece_off[n+1], durations[P], coeffs[P, 9, 6], knots_xy[P + n, 2] (candidate k's knots start at piece_off[k] + k)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        n = len(idx)
+        npc = self.n_pieces() if n_pieces is None else n_pieces
+        cap = int(npc[idx].sum()) if n else 0
+        off = np.zeros(n + 1, dtype=np.int32)
+        dur = np.zeros(cap)
+        coef = np.zeros(cap * 54)
+        kn = np.zeros(2 * (cap + n))
+        _chk(self.L, self.L.topay_get_results(self.h, n, _ip(idx), cap, _ip(off), _dp(dur), _dp(coef), _dp(kn)))
+        return dict(piece_off=off, durations=dur, coeffs=coef.reshape(cap, 9, 6), knots_xy=kn.reshape(cap + n, 2))
+
+    def polytraj_msg(self, i):
+        """Candidate i in the field layout of planner/msg/PolyTraj.msg: (order, coeff[N, 9, 6] f32, durations[N] f32, directions[N] i8)."""
+        N = int(self.n_pieces()[i])
+        order = C.c_ubyte(0)
+        coef = np.zeros(max(N, 1) * 54, dtype=np.float32)
+        dur = np.zeros(max(N, 1), dtype=np.float32)
+        dirs = np.zeros(max(N, 1), dtype=np.int8)
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_get_polytraj_msg(self.h, i, max(N, 1), C.byref(order), coef.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   dur.ctypes.data_as(C.POINTER(C.c_float)), dirs.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                   C.byref(n)))
+        return order.value, coef[:N * 54].reshape(N, 9, 6), dur[:N], dirs[:N]
 
     def stats(self):
         s = np.zeros(self.batch * 8, dtype=np.int32)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <numeric>
 #include <cstdlib>
@@ -384,6 +385,24 @@ __global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cse
   F.report = nullptr;
   F.feasible = nullptr;
   playback(F, nq, times, states, seq_out, nseq_out);
+}
+
+// getTraj() of a selection of candidates, packed by pieces (topay_get_results): one workgroup per selected candidate
+__global__ void k_gather_results(DevBatch Bt, int n, const int* idx, const int* piece_off, double* durations, double* coeffs,
+                                 double* knots) {
+  const int k = blockIdx.x;
+  if (k >= n) return;
+  const int b = idx[k];
+  const int N = piece_off[k + 1] - piece_off[k];
+  if (N <= 0) return;
+  const int rows = 6 * N, p0 = piece_off[k];
+  const double* cm = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;   // [9][rows], element d * rows + 6 p + k = coefficient of t^k
+  for (int t = threadIdx.x; t < N * 54; t += blockDim.x) {
+    const int p = t / 54, r = t - 54 * p, d = r / 6, kk = r - 6 * d;
+    coeffs[(size_t)p0 * 54 + t] = cm[(size_t)d * rows + 6 * p + 5 - kk];   // per piece 9 x 6, highest order first
+  }
+  for (int t = threadIdx.x; t < N; t += blockDim.x) durations[p0 + t] = Bt.T[(size_t)b * Bt.Nmax + t];
+  for (int t = threadIdx.x; t < 2 * (N + 1); t += blockDim.x) knots[2 * (size_t)(p0 + k) + t] = Bt.knots[(size_t)b * 2 * (Bt.Nmax + 1) + t];
 }
 
 // GridMap::isWholeBodyCollision for a batch of states
@@ -1651,6 +1670,69 @@ topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, i
   }
   if (knots_xy)
     HIPCHK(memcpy_sync(c, knots_xy, c->knots.as<double>() + (size_t)i * 2 * (c->Nmax + 1), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+topay_status topay_get_results(topay_ctx* c, int n, const int* idx, int cap_pieces, int* piece_off, double* durations,
+                               double* coeffs, double* knots_xy) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (n < 0 || (n > 0 && (!idx || !piece_off))) return TOPAY_ERR_INVALID_ARG;
+  if (n == 0) return TOPAY_OK;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<int> off((size_t)n + 1, 0);
+  for (int k = 0; k < n; k++) {
+    if (idx[k] < 0 || idx[k] >= c->B) return TOPAY_ERR_INVALID_ARG;
+    off[k + 1] = off[k] + c->hN[idx[k]];
+  }
+  const int np = off[n];
+  memcpy(piece_off, off.data(), ((size_t)n + 1) * sizeof(int));
+  if (np > cap_pieces) { set_err("topay_get_results: cap_pieces too small for the selection"); return TOPAY_ERR_INVALID_ARG; }
+  if (np == 0 || (!durations && !coeffs && !knots_xy)) return TOPAY_OK;
+  // device staging: idx | piece_off | durations | coeffs | knots, one kernel, one copy back
+  const size_t ints = (size_t)2 * n + 1, dbl = (size_t)np + (size_t)np * 54 + (size_t)2 * (np + n);
+  topay_status s;
+  if ((s = c->pb_io.ensure(ints * 4 + 8 + dbl * 8)) != TOPAY_OK) return s;
+  int* d_idx = c->pb_io.as<int>();
+  int* d_off = d_idx + n;
+  double* d_dur = (double*)(((uintptr_t)(d_off + n + 1) + 7) & ~(uintptr_t)7);
+  double* d_coef = d_dur + np;
+  double* d_kn = d_coef + (size_t)np * 54;
+  HIPCHK(hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(64), 0, c->stream, c->db, n, (const int*)d_idx, (const int*)d_off, d_dur,
+                     d_coef, d_kn);
+  HIPCHK(hipGetLastError());
+  std::vector<double> host(dbl);
+  HIPCHK(memcpy_sync(c, host.data(), d_dur, dbl * 8, hipMemcpyDeviceToHost));
+  if (durations) memcpy(durations, host.data(), (size_t)np * 8);
+  if (coeffs) memcpy(coeffs, host.data() + np, (size_t)np * 54 * 8);
+  if (knots_xy) memcpy(knots_xy, host.data() + np + (size_t)np * 54, (size_t)2 * (np + n) * 8);
+  return TOPAY_OK;
+}
+
+topay_status topay_get_polytraj_msg(topay_ctx* c, int i, int cap_pieces, unsigned char* order, float* coeff, float* durations,
+                                    signed char* directions, int* n_pieces) {
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
+  const int N = c->hN[i];
+  if (n_pieces) *n_pieces = N;
+  if (order) *order = 5;
+  if (N == 0) return TOPAY_OK;
+  if (N > cap_pieces) return TOPAY_ERR_INVALID_ARG;
+  std::vector<double> dur((size_t)N), cf((size_t)N * 54);
+  topay_status s = topay_get_result(c, i, nullptr, nullptr, nullptr, dur.data(), cf.data(), nullptr);
+  if (s != TOPAY_OK) return s;
+  for (int p = 0; p < N; p++) {
+    if (durations) durations[p] = (float)dur[p];
+    if (coeff)
+      for (int t = 0; t < 54; t++) coeff[(size_t)p * 54 + t] = (float)cf[(size_t)p * 54 + t];
+    if (directions) {
+      // arc-length rate (dimension 1) at the middle of the piece; coefficients are highest order first
+      const double* a = &cf[(size_t)p * 54 + 6], t = 0.5 * dur[p];
+      const double sd = ((((5.0 * a[0]) * t + 4.0 * a[1]) * t + 3.0 * a[2]) * t + 2.0 * a[3]) * t + a[4];
+      directions[p] = sd < 0.0 ? -1 : 1;
+    }
+  }
   return TOPAY_OK;
 }
 

@@ -18,17 +18,20 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durations):
+def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durations, return_winners=False):
     """Local argmin-by-duration per scenario -> records [n_scen, 6] (float64).
-    scen_of_traj[b] is the (global) scenario id of trajectory b; durations[b] its total duration."""
+    scen_of_traj[b] is the (global) scenario id of trajectory b; durations[b] its total duration; success[b] is what the
+    planner requires of a candidate (planner.cpp:878-885: optimizeTraj's return value AND printConstraintsSituations).
+    With return_winners also the trajectory indices of the per-scenario winners (scenarios without one are left out)."""
     scenario_ids = np.asarray(scenario_ids)
     scen_of_traj = np.asarray(scen_of_traj)
     recs = np.zeros((len(scenario_ids), RECORD_WIDTH))
     recs[:, 0] = scenario_ids
     recs[:, 1] = -1.0
     recs[:, 4:] = np.nan
+    winners = []
     if len(scen_of_traj) == 0:
-        return recs
+        return (recs, np.zeros(0, dtype=np.int32)) if return_winners else recs
     # first trajectory of every scenario (candidate index = position - first) and the best successful one
     order = np.argsort(scen_of_traj, kind="stable")
     s_sorted = scen_of_traj[order]
@@ -51,7 +54,8 @@ def scenario_records(scenario_ids, scen_of_traj, success, cost, n_pieces, durati
             if r is None:
                 continue
             recs[r, 1:] = (best - first_pos[sid], 1.0, n_pieces[best], cost[best], durations[best])
-    return recs
+            winners.append(best)
+    return (recs, np.array(winners, dtype=np.int32)) if return_winners else recs
 
 
 def gather_records_begin(local_records, max_rows, device=None):
