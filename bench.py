@@ -104,7 +104,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     from topay_amd import api, dist as tdist
-    from topay_amd.harness import workload as wl
+    from harness import workload as wl
 
     # ---- synthetic inputs (CPU harness, untimed): S scenarios of this rank, one map each
     S, Ccand = args.scenarios, args.candidates
@@ -184,6 +184,19 @@ def main():
     tr0 = time.perf_counter()
 
     winners = {}
+    sent = []                            # local records of the gathers in flight, oldest first
+    gather_stats = {"gathers": 0, "rows": 0, "own_rows_match": True}
+
+    def check_gather(rows):
+        # every rank finds its own records, bit for bit, in what came back over RCCL (with one rank: the whole result)
+        mine = sent.pop(0)
+        got = rows[np.isin(rows[:, 0], mine[:, 0])]
+        got = got[np.argsort(got[:, 0], kind="stable")]
+        ref = mine[np.argsort(mine[:, 0], kind="stable")]
+        same = got.shape == ref.shape and bool(np.all((got == ref) | (np.isnan(got) & np.isnan(ref))))
+        gather_stats["gathers"] += 1
+        gather_stats["rows"] = int(rows.shape[0])
+        gather_stats["own_rows_match"] = gather_stats["own_rows_match"] and same
 
     def finish(o_):
         ta = time.perf_counter()
@@ -207,8 +220,9 @@ def main():
                 deferred.append(recs)    # gathered after the last step of the run, still inside the timed region
             else:
                 gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
+                sent.append(recs)
                 while len(gathers) > 1:
-                    tdist.gather_records_end(gathers.pop(0))
+                    check_gather(tdist.gather_records_end(gathers.pop(0)))
             if trace:
                 print(f"[trace] finish at {1e3 * (ta - tr0):.0f} ms: wait {1e3 * (tb_ - ta):.1f}, records {1e3 * (tc - tb_):.1f}, "
                       f"gather {1e3 * (time.perf_counter() - tc):.1f} ms", file=sys.stderr)
@@ -226,9 +240,10 @@ def main():
         for i in range(max(0, nsteps - depth_), nsteps):
             out_.append(finish(opts[i % depth_]))
         while deferred:                  # chained run: the device is free again, one gather per step
+            sent.append(deferred[0])
             gathers.append(tdist.gather_records_begin(deferred.pop(0), max_rows=S, device=dev))
         while gathers:                   # every step's records are on every rank before the step counts as done
-            tdist.gather_records_end(gathers.pop(0))
+            check_gather(tdist.gather_records_end(gathers.pop(0)))
         return out_
 
     run(args.warmup)
@@ -342,6 +357,8 @@ def main():
             "h2d_bytes_per_step": int(tb.paths.nbytes + tb.lens.nbytes + 4 * B),
             "winners_per_step": int(winners.get("n", 0)),
             "d2h_winner_bytes_per_step": int(sum(v.nbytes for v in winners["last"].values())) if "last" in winners else 0,
+            "record_gather": (dict(gather_stats, collective="RCCL all-gather of 6 x f64 per scenario", rows_expected=int(S * world))
+                              if distributed else None),
             "setup_seconds_untimed": setup_s,
             "esdf_build_ms_gpu_untimed": edt_ms,
             "config1_latency": cfg1,

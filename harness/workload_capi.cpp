@@ -1,5 +1,5 @@
 // C entry points of the synthetic-workload harness (see workload.hpp).  Loaded through ctypes by
-// topay_amd/harness/workload.py; used by bench.py and tests to build identical inputs for the HIP
+// harness/workload.py; used by bench.py and tests to build identical inputs for the HIP
 // path and the oracle.
 #include <atomic>
 

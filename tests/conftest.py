@@ -19,7 +19,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def built_libs():
     """CPU-side libraries: oracle, workload harness, lane-emulator build of the kernels (all test infrastructure)."""
-    for d in ("oracle", os.path.join("topay_amd", "harness"), os.path.join("tests", "emu")):
+    for d in ("oracle", "harness", os.path.join("tests", "emu")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, d)])
     return True
 
@@ -28,7 +28,7 @@ def built_libs():
 def cuboids_small(built_libs):
     """3 scenarios x 2 candidates on the seed-42 cuboids map: N = 4, 7, 8, 10, 8, 11 pieces."""
     from oracle import oracle as orc
-    from topay_amd.harness import workload as wl
+    from harness import workload as wl
 
     w, lens, paths, scen = wl.cuboids_batch(3, 2)
     m = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
-from topay_amd.harness import workload as wl  # noqa: E402
+from harness import workload as wl  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

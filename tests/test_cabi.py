@@ -109,3 +109,16 @@ def test_header_is_plain_c99():
     src = '#include "topay.h"\nint main(void) { topay_params_t p; return (int)sizeof(p) == 0; }\n'
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c", "-"],
                    input=src, text=True, check=True)
+
+
+def test_reference_side_adapter_compiles_against_the_header():
+    """examples/moma_traj_opt_hip.h is the class a TopAY maintainer drops into the reference: the
+    reference's optimizeTraj / getTraj / traj_cost / printConstraintsSituations surface over the C-ABI, written against
+    the real GridMap accessors (grid_map.h:85-86, 179, 203, 206, 213-216).  Eigen and ROS are absent here, so it is
+    syntax-checked against name-and-signature stand-ins (tests/stubs/); a signature drift of include/topay.h breaks it."""
+    import subprocess
+
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "examples"),
+                        os.path.join(ROOT, "examples", "adapter_syntax_check.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

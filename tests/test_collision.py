@@ -1,11 +1,11 @@
 """GridMap::isWholeBodyCollision (grid_map.h:613-650) on the device against the CPU restatement of the workload
-harness (topay_amd/harness/workload.hpp: RobotModel::isWholeBodyCollision, same file:line citations)."""
+harness (harness/workload.hpp: RobotModel::isWholeBodyCollision, same file:line citations)."""
 import numpy as np
 import pytest
 
 from conftest import EMU_LIB, set_map
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 
 def _states(w, n, seed):

@@ -1,5 +1,5 @@
 """ESDF construction on the device (GridMap::updateESDF, grid_map.cpp:89-521) against the CPU restatement used by the
-workload harness (topay_amd/harness/workload.hpp: fillESDF / updateESDF2d / updateESDF3d, same file:line citations):
+workload harness (harness/workload.hpp: fillESDF / updateESDF2d / updateESDF3d, same file:line citations):
 bit-exact, as the arithmetic is integer index math, one division per envelope test and res * sqrt at the end."""
 import numpy as np
 import pytest
@@ -7,7 +7,7 @@ import pytest
 from conftest import EMU_LIB, set_map
 from oracle import oracle as orc
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 
 def _build_and_compare(opt, w):

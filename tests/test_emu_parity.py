@@ -8,7 +8,7 @@ import pytest
 from conftest import EMU_LIB, serpentine_path, set_map
 from oracle import oracle as orc
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 
 @pytest.fixture(scope="module")

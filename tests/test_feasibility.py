@@ -7,7 +7,7 @@ import pytest
 from conftest import EMU_LIB, set_map
 from oracle import oracle as orc
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 
 def _oracle_gate(m, path, x, alm):

@@ -15,7 +15,7 @@ import pytest
 from conftest import EMU_LIB, serpentine_path, set_map
 from oracle import oracle as orc
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 pytestmark = pytest.mark.gpu
 
@@ -686,3 +686,28 @@ def test_chain_slot_reuse_with_many_contexts_in_flight(monkeypatch):
     for o in ctxs:
         o.close()
     tb.close()
+
+
+@pytest.mark.gpu
+def test_rccl_record_gather_on_one_gpu():
+    """The multi-GPU code path of bench.py (RCCL process group, per-scenario record all-gather overlapped with the next
+    batch's persistent solve, max-over-ranks timing) on the one GPU there is: one rank under torch.distributed.run with
+    TOPAY_FORCE_DIST=1.  The launcher is started before anything touches the GPU in that process tree; this test only
+    reads the JSON line.  What came back over RCCL must be the rank's own records, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOPAY_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scenarios", "64",
+           "--no-cpu-baseline", "--no-config1", "--no-serial"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    g = out["config"]["record_gather"]
+    assert g is not None and g["gathers"] >= 4 and g["own_rows_match"] is True and g["rows"] == 64 == g["rows_expected"]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["n_not_launched"] == 0

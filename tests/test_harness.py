@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 
 def test_edt_single_voxel_is_analytic():
@@ -57,7 +57,7 @@ def test_tables_batch_one_map_per_scenario():
 def test_tables_batch_can_drop_cpu_esdf3d_without_changing_the_inputs():
     """bench.py keeps the CPU-built 3-D distance field only for the scenarios the CPU baseline solves; paths, occupancy
     grids and the 2-D field must not depend on that."""
-    from topay_amd.harness import workload as wl
+    from harness import workload as wl
 
     a = wl.TablesBatch(4, 2, base_seed=4242, nthreads=4)
     b = wl.TablesBatch(4, 2, base_seed=4242, nthreads=4, keep_esdf3d=1)

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle as orc
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 world, start, goal, lens, paths = wl.tables_scenario(0, 64)
 m = orc.MapView(world.origin, world.res, world.dims, world.min_b, world.max_b, world.esdf2d, world.esdf3d)

@@ -6,7 +6,7 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
     except Exception as e: print(f, "n/a")
 os.system("lscpu | egrep 'Model name|Socket|Core|Thread|MHz|NUMA node\\(s\\)' ; cat /proc/loadavg")
 from oracle import oracle as orc
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 tb = wl.TablesBatch(64, 8, base_seed=42, nthreads=0)
 views = []
 for s in tb.scenarios:

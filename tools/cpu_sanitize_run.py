@@ -1,7 +1,7 @@
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 LIB = sys.argv[1]
 w, lens, paths, scen = wl.cuboids_batch(3, 2)
 p = api.default_params(api.load(LIB))

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import set_map, serpentine_path
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 lib = os.environ.get("TOPAY_LIB")
 w, lens, paths, scen = wl.cuboids_batch(3, 2)
 for L in [float(a) for a in sys.argv[1:]] or [24.0, 40.0, 62.0]:

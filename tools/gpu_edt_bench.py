@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 t = time.time(); tb = wl.TablesBatch(S, 1, base_seed=42, nthreads=0); cpu_s = time.time() - t
 worlds = [tb.world(s) for s in tb.scenarios]

@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 from topay_amd import api
 S = int(os.environ.get("S", "256")); R = int(os.environ.get("R", "10")); stage = int(os.environ.get("STAGE", "2"))
 gpu = api.MomaTrajOptBatch(device=0)

@@ -7,7 +7,7 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
 dev = torch.device("cuda:0")

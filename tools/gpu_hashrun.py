@@ -1,7 +1,7 @@
 import sys, hashlib, numpy as np
 sys.path.insert(0,'.')
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 tb = wl.TablesBatch(256, 8, base_seed=42, nthreads=0)
 opt = api.MomaTrajOptBatch(device=0)
 slot = {}

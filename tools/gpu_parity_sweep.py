@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle as orc
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 tb = wl.TablesBatch(256, 8, base_seed=7000, nthreads=0)
 opt = api.MomaTrajOptBatch(device=0)
 slot = {}

@@ -3,7 +3,7 @@ import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 tb = wl.TablesBatch(512, 8, base_seed=42, nthreads=0)
 opt = api.MomaTrajOptBatch(device=0)
 slot = {}

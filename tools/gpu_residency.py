@@ -3,7 +3,7 @@ import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nmax_only = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # keep only candidates with N <= this (0 = all)
 tb = wl.TablesBatch(S, 8, base_seed=42, nthreads=0)

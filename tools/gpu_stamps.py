@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 from topay_amd import api
 gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB", "topay_amd/lib/libtopay_hip_stamps.so"))
 names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]

@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 from topay_amd import api
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 tb = wl.TablesBatch(512, 8, base_seed=42, nthreads=0)

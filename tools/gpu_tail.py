@@ -3,7 +3,7 @@ import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from topay_amd import api
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 tb = wl.TablesBatch(S, 8, base_seed=42, nthreads=0)
 opt = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB"))

@@ -9,7 +9,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
-from topay_amd.harness import workload as wl
+from harness import workload as wl
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 Cn = int(sys.argv[2]) if len(sys.argv) > 2 else 8
