@@ -290,6 +290,44 @@ struct GridMap {
     }
   }
 
+  // One signed 2-D field from an occupancy grid (1 = seed of the positive part, 0 = seed of the negative part): the
+  // construction grid_map.cpp:125-207 applies to occ_buffer_2d and, with other seeds, at 211-279, 283-351 and 355-423.
+  void signedField2d(const std::vector<char>& occ, std::vector<double>& out) const {
+    const int rows = voxel_num[0], cols = voxel_num[1];
+    const int mx = std::max(rows, cols);
+    std::vector<double> tmp((size_t)rows * cols), dist((size_t)rows * cols), neg((size_t)rows * cols);
+    std::vector<int> v(mx + 2);
+    std::vector<double> z(mx + 2);
+    const double DMAX = std::numeric_limits<double>::max();
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<double>& outbuf = pass == 0 ? dist : neg;
+      for (int x = 0; x < rows; x++)
+        fillESDF([&](int y) { return (occ[addr2(x, y)] == 1) == (pass == 0) ? 0.0 : DMAX; },
+                 [&](int y, double val) { tmp[addr2(x, y)] = val; }, 0, cols - 1, cols, v.data(), z.data());
+      for (int y = 0; y < cols; y++)
+        fillESDF([&](int x) { return tmp[addr2(x, y)]; },
+                 [&](int x, double val) { outbuf[addr2(x, y)] = resolution * std::sqrt(val); }, 0, rows - 1, rows,
+                 v.data(), z.data());
+    }
+    out.assign((size_t)rows * cols, 0.0);
+    for (size_t i = 0; i < out.size(); i++) {
+      out[i] = dist[i];
+      if (neg[i] > 0.0) out[i] += (-neg[i] + resolution);
+    }
+  }
+  // The two front-end fields of updateESDF: esdf_buffer_2d_inflate (grid_map.cpp:355-423) and esdf_buffer_2d_critical
+  // (211-279, overwritten by its own inflation at 283-351).  occ_crit = occ_buffer_2d_critical (733-747).
+  void frontEndFields(const std::vector<char>& occ_crit, double chassis_radius, std::vector<double>& inflate,
+                      std::vector<double>& critical) const {
+    std::vector<char> seeds(esdf2d.size());
+    for (size_t i = 0; i < seeds.size(); i++) seeds[i] = esdf2d[i] < chassis_radius ? 1 : 0;
+    signedField2d(seeds, inflate);
+    std::vector<double> crit0;
+    signedField2d(occ_crit, crit0);
+    for (size_t i = 0; i < seeds.size(); i++) seeds[i] = crit0[i] < chassis_radius ? 1 : 0;
+    signedField2d(seeds, critical);
+  }
+
   // 2-D signed EDT — grid_map.cpp:125-207
   void updateESDF2d() {
     const int rows = voxel_num[0], cols = voxel_num[1];

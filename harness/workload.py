@@ -231,3 +231,21 @@ class TablesBatch:
             self.close()
         except Exception:
             pass
+
+
+def front_end_fields(occ2d, occ3d, dims, res, chassis_radius=0.4, occ2d_critical=None):
+    """CPU construction of GridMap's esdf_buffer_2d_inflate and esdf_buffer_2d_critical (grid_map.cpp:211-423) from the
+    occupancy grids -- the checker of topay_build_esdf_fields.  Returns (inflate, critical)."""
+    L = lib()
+    nx, ny, nz = (int(x) for x in dims)
+    o2 = np.ascontiguousarray(occ2d, dtype=np.int8)
+    o3 = np.ascontiguousarray(occ3d, dtype=np.int8)
+    oc = None if occ2d_critical is None else np.ascontiguousarray(occ2d_critical, dtype=np.int8)
+    inf = np.zeros(nx * ny)
+    cr = np.zeros(nx * ny)
+    P8 = C.POINTER(C.c_int8)
+    L.wl_edt_front_end_fields.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, c_dp, c_dp]
+    L.wl_edt_front_end_fields.restype = None
+    L.wl_edt_front_end_fields(o2.ctypes.data_as(P8), None if oc is None else oc.ctypes.data_as(P8), o3.ctypes.data_as(P8), nx, ny, nz,
+                              float(res), float(chassis_radius), inf.ctypes.data_as(c_dp), cr.ctypes.data_as(c_dp))
+    return inf, cr

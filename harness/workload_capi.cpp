@@ -89,6 +89,26 @@ void wl_edt(const char* occ2d, const char* occ3d, int nx, int ny, int nz, double
 }
 
 
+// the two front-end fields of updateESDF from the occupancy grids (occ2d_critical may be null: projection of occ3d)
+void wl_edt_front_end_fields(const char* occ2d, const char* occ2d_critical, const char* occ3d, int nx, int ny, int nz, double res,
+                             double chassis_radius, double* inflate, double* critical) {
+  GridMap gm;
+  gm.init(nx * res, ny * res, nz * res, res);
+  gm.voxel_num[0] = nx; gm.voxel_num[1] = ny; gm.voxel_num[2] = nz;
+  gm.occ2d.assign(occ2d, occ2d + (size_t)nx * ny);
+  gm.updateESDF2d();
+  std::vector<char> crit((size_t)nx * ny, 0);
+  if (occ2d_critical) crit.assign(occ2d_critical, occ2d_critical + (size_t)nx * ny);
+  else
+    for (size_t c = 0; c < crit.size(); c++)
+      for (int z = 0; z < nz; z++)
+        if (occ3d[c * nz + z] == 1) crit[c] = 1;
+  std::vector<double> inf, cr;
+  gm.frontEndFields(crit, chassis_radius, inf, cr);
+  std::memcpy(inflate, inf.data(), inf.size() * sizeof(double));
+  std::memcpy(critical, cr.data(), cr.size() * sizeof(double));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Benchmark batch for the "tables" scene: S scenarios, each with its OWN map (the reference regenerates the
 // map every episode with 1x1 m keep-outs at start and goal, planner.cpp:514-521, grid_map.cpp:755-772),

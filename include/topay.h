@@ -159,6 +159,19 @@ topay_status topay_build_esdf_batch(topay_ctx* ctx, int n_maps, int first_map_id
                                     const signed char* occ2d, const signed char* occ3d);
 topay_status topay_get_map(topay_ctx* ctx, int map_id, double* esdf2d, double* esdf3d, double* build_ms);
 
+/* All five fields of GridMap::updateESDF (src/map/src/grid_map.cpp:125-521).  Besides esdf2d and esdf3d (above) the
+ * reference builds two more 2-D fields for its front-end:
+ *   esdf_buffer_2d_inflate   (355-423): the signed field of the cells where esdf2d < chassis_colli_radius;
+ *   esdf_buffer_2d_critical  (211-351): the signed field of occ_buffer_2d_critical (any cloud point above the cell,
+ *                            whatever its height, grid_map.cpp:733-747), then -- into the same buffer, as the reference
+ *                            does at line 348 -- the field of the cells where that one is < chassis_colli_radius.
+ * occ2d_critical may be NULL: the projection of occ3d onto the plane is used (what the reference's fill produces for a
+ * cloud inside the map's height).  topay_build_esdf / _batch are this call with occ2d_critical = NULL.
+ * topay_get_map_fields copies the two extra fields of a built map back (either pointer may be NULL). */
+topay_status topay_build_esdf_fields(topay_ctx* ctx, int n_maps, int first_map_id, const topay_map_desc_t* desc,
+                                     const signed char* occ2d, const signed char* occ2d_critical, const signed char* occ3d);
+topay_status topay_get_map_fields(topay_ctx* ctx, int map_id, double* esdf2d_inflate, double* esdf2d_critical);
+
 /* == optimizeTraj lines 146-357 for every batch member.
  *   path_len[b]      number of 10-d states of candidate b
  *   init_paths       ragged, sum(path_len) x 10, row-major (x, y, theta, q1..q7)

@@ -14,6 +14,11 @@ def _build_and_compare(opt, w):
     opt.build_esdf(w.origin, w.res, w.dims, w.min_b, w.max_b, w.occ2d, w.occ3d)
     e2, e3, ms = opt.get_map()
     assert (e2 == w.esdf2d).all() and (e3 == w.esdf3d).all()
+    # the two front-end fields of updateESDF (inflate, critical -> critical-inflate; grid_map.cpp:211-423)
+    inf, crit = opt.get_map_fields()
+    inf_ref, crit_ref = wl.front_end_fields(w.occ2d, w.occ3d, w.dims, w.res)
+    assert (inf == inf_ref).all() and (crit == crit_ref).all()
+    assert (inf <= e2 + 1e-12).all() and (np.abs(inf - e2) > 0.05).any()   # inflating obstacles brings them closer
     return ms
 
 
@@ -44,6 +49,18 @@ def test_edt_edge_maps():
     assert np.allclose(e3[free], d[free], rtol=0, atol=1e-12)
     d2 = w.res * np.sqrt((X[:, :, 0] - 10.0) ** 2 + (Y[:, :, 0] - 12.0) ** 2)
     assert np.allclose(e2[d2 > 0], d2[d2 > 0], rtol=0, atol=1e-12)
+    # an explicit critical occupancy (a second pillar that exists only above the chassis height) enters the critical
+    # field and not the others; inflate = distance to the disc of cells closer than the chassis radius
+    crit_occ = occ2.copy()
+    crit_occ[25 * ny + 30] = 1
+    emu.build_esdf_fields(w.origin, w.res, w.dims, w.min_b, w.max_b, occ2, crit_occ, occ3)
+    inf, crit = emu.get_map_fields()
+    inf_ref, crit_ref = wl.front_end_fields(occ2, occ3, w.dims, w.res, occ2d_critical=crit_occ)
+    assert (inf == inf_ref).all() and (crit == crit_ref).all()
+    inf = inf.reshape(nx, ny)
+    crit = crit.reshape(nx, ny)
+    assert inf[10, 12] < 0 and inf[10, 12 + 8] > 0 and abs(inf[10, 12 + 8] - (d2[10, 12 + 8] - 0.4)) < 0.11
+    assert crit[25, 30] < 0 and inf[25, 30] > 0
     w.close()
 
 

@@ -97,6 +97,9 @@ def load(path=None):
     L.topay_get_map.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
     L.topay_build_esdf_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8),
                                          C.POINTER(C.c_int8)]
+    L.topay_build_esdf_fields.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(MapDesc), C.POINTER(C.c_int8), C.POINTER(C.c_int8),
+                                          C.POINTER(C.c_int8)]
+    L.topay_get_map_fields.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp]
     L.topay_get_total_durations.argtypes = [C.c_void_p, c_dp]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
     L.topay_feasibility_report.argtypes = [C.c_void_p, c_ip, c_ip, c_dp]
@@ -309,6 +312,28 @@ class MomaTrajOptBatch:
                                                    o3.ctypes.data_as(C.POINTER(C.c_int8))))
         for k in range(n_maps):
             self._map_dims[first_map_id + k] = tuple(int(x) for x in dims)
+
+    def build_esdf_fields(self, origin, res, dims, min_b, max_b, occ2d, occ2d_critical, occ3d, map_id=0):
+        """GridMap::updateESDF in full (also the inflate / critical 2-D fields); occ2d_critical may be None."""
+        d = MapDesc()
+        for k in range(3):
+            d.origin[k] = origin[k]; d.dims[k] = int(dims[k]); d.min_boundary[k] = min_b[k]; d.max_boundary[k] = max_b[k]
+        d.resolution = res
+        o2 = np.ascontiguousarray(occ2d, dtype=np.int8)
+        o3 = np.ascontiguousarray(occ3d, dtype=np.int8)
+        oc = None if occ2d_critical is None else np.ascontiguousarray(occ2d_critical, dtype=np.int8)
+        P8 = C.POINTER(C.c_int8)
+        _chk(self.L, self.L.topay_build_esdf_fields(self.h, 1, map_id, C.byref(d), o2.ctypes.data_as(P8),
+                                                    None if oc is None else oc.ctypes.data_as(P8), o3.ctypes.data_as(P8)))
+        self._map_dims[map_id] = tuple(int(x) for x in dims)
+
+    def get_map_fields(self, map_id=0):
+        """(esdf2d_inflate, esdf2d_critical) of a map built on the device."""
+        nx, ny, nz = self._map_dims[map_id]
+        a = np.zeros(nx * ny)
+        b = np.zeros(nx * ny)
+        _chk(self.L, self.L.topay_get_map_fields(self.h, map_id, _dp(a), _dp(b)))
+        return a, b
 
     def get_map(self, map_id=0):
         """(esdf2d, esdf3d, build_ms) of a resident map."""

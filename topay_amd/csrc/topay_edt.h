@@ -107,4 +107,21 @@ __global__ void k_edt_pass(EdtPass P, const signed char* occ, const double* src,
   }
 }
 
+// Seeds of the "inflate" fields (grid_map.cpp:283-300, 355-372): a cell is occupied when the field it is derived from
+// is below the chassis radius there.
+__global__ void k_edt_threshold(const double* field, double thr, signed char* occ, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) occ[i] = field[i] < thr ? 1 : 0;
+}
+// occ_buffer_2d_critical (grid_map.cpp:733-747): any point of the cloud above the cell, i.e. the 3-D occupancy
+// projected onto the plane (used when the caller does not hand the buffer over).
+__global__ void k_edt_project(const signed char* occ3, signed char* occ2, long long n2, int nz, long long maps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2 * maps) return;
+  const signed char* col = occ3 + i * nz;   // cell (map, x, y): nz consecutive bytes
+  signed char any = 0;
+  for (int z = 0; z < nz; z++) any |= (col[z] == 1);
+  occ2[i] = any;
+}
+
 }  // namespace topay

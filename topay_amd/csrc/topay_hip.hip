@@ -520,6 +520,7 @@ struct topay_ctx {
   // maps
   std::vector<DevMap> hmaps = std::vector<DevMap>(TOPAY_MAX_MAPS);
   std::vector<DevBuf> map2d = std::vector<DevBuf>(TOPAY_MAX_MAPS), map3d = std::vector<DevBuf>(TOPAY_MAX_MAPS);
+  std::vector<DevBuf> map2d_inf = std::vector<DevBuf>(TOPAY_MAX_MAPS), map2d_crit = std::vector<DevBuf>(TOPAY_MAX_MAPS);
   DevBuf dmaps;
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
   // batch
@@ -765,7 +766,7 @@ void topay_destroy(topay_ctx* c) {
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
   for (DevBuf* b : bufs) b->release();
-  for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); }
+  for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); c->map2d_inf[i].release(); c->map2d_crit[i].release(); }
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     if (c->bevent[k]) (void)hipEventDestroy(c->bevent[k]);
     if (c->bstream[k] && c->bstream[k] != c->stream) (void)hipStreamDestroy(c->bstream[k]);
@@ -802,6 +803,10 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   m.res_inv = 1.0 / desc->resolution;  // grid_map.cpp:41
   m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
   m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
+  m.esdf2d_inflate = nullptr;
+  m.esdf2d_critical = nullptr;
+  c->map2d_inf[map_id].release();
+  c->map2d_crit[map_id].release();
   c->have_map[map_id] = 1;
   HIPCHK(memcpy_sync(c, (char*)c->dmaps.p + sizeof(DevMap) * map_id, &c->hmaps[map_id], sizeof(DevMap), hipMemcpyHostToDevice));
   return TOPAY_OK;
@@ -864,8 +869,8 @@ static topay_status run_init(topay_ctx* c) {
 // occ3d[x*ny*nz + y*nz + z].  The map slots then hold the result exactly as topay_set_map would.  A batch of maps
 // of equal dimensions (the benchmark loop: one map per scenario) is built by the same launches, blockIdx.y = map:
 // a single 200 x 200 x 16 map has too few lines to fill the device.
-topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, const topay_map_desc_t* desc,
-                                    const signed char* occ2d, const signed char* occ3d) {
+topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id, const topay_map_desc_t* desc,
+                                     const signed char* occ2d, const signed char* occ2d_critical, const signed char* occ3d) {
   if (!c || !desc || !occ2d || !occ3d || n_maps <= 0 || first_map_id < 0 || first_map_id + n_maps > TOPAY_MAX_MAPS)
     return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -874,24 +879,30 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
   const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, M = (size_t)n_maps;
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
   topay_status s;
-  if ((s = c->edt_occ.ensure(M * (n3 + n2))) != TOPAY_OK) return s;
+  if ((s = c->edt_occ.ensure(M * (n3 + 3 * n2))) != TOPAY_OK) return s;   // 3-D, 2-D, 2-D critical, 2-D scratch
   if ((s = c->edt_tmp1.ensure(M * n3 * 8)) != TOPAY_OK) return s;
   if ((s = c->edt_tmp2.ensure(M * n3 * 8)) != TOPAY_OK) return s;
   if ((s = c->edt_out3.ensure(M * n3 * 8)) != TOPAY_OK) return s;
-  if ((s = c->edt_out2.ensure(M * n2 * 8)) != TOPAY_OK) return s;
+  if ((s = c->edt_out2.ensure(M * n2 * 8 * 4)) != TOPAY_OK) return s;   // plain, inflate, critical, scratch
   // workspace for the envelope stacks of the pass with the most (lines x cells), per map
   const size_t ws_elems = std::max(std::max((size_t)nx * ny * (nz + 2), (size_t)nx * nz * (ny + 2)), (size_t)ny * nz * (nx + 2));
   if ((s = c->edt_v.ensure(M * ws_elems * 4)) != TOPAY_OK) return s;
   if ((s = c->edt_z.ensure(M * ws_elems * 8)) != TOPAY_OK) return s;
   signed char* d_occ3 = c->edt_occ.as<signed char>();
   signed char* d_occ2 = d_occ3 + M * n3;
+  signed char* d_occ2c = d_occ2 + M * n2;
+  signed char* d_occ2t = d_occ2c + M * n2;
   HIPCHK(hipMemcpyAsync(d_occ3, occ3d, M * n3, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d_occ2, occ2d, M * n2, hipMemcpyHostToDevice, c->stream));
+  if (occ2d_critical) HIPCHK(hipMemcpyAsync(d_occ2c, occ2d_critical, M * n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
   double* t1 = c->edt_tmp1.as<double>();
   double* t2 = c->edt_tmp2.as<double>();
   double* e3 = c->edt_out3.as<double>();
   double* e2 = c->edt_out2.as<double>();
+  double* e2i = e2 + M * n2;       // inflate
+  double* e2c = e2i + M * n2;      // critical (holds the critical-inflate field at the end, as the reference's buffer does)
+  double* e2s = e2c + M * n2;      // scratch: the plain critical field
   int* vws = c->edt_v.as<int>();
   double* zws = c->edt_z.as<double>();
   const double res = desc->resolution;
@@ -924,12 +935,34 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
     if ((s = launch(k_edt_pass<0, 0, 0>, k_edt_pass<0, 0, 1>, pz, (long long)n3, d_occ3, nullptr, t1, pass)) != TOPAY_OK) return s;
     if ((s = launch(k_edt_pass<1, 0, 0>, k_edt_pass<1, 0, 1>, py, (long long)n3, nullptr, t1, t2, pass)) != TOPAY_OK) return s;
     if ((s = launch(k_edt_pass<1, 1, 0>, k_edt_pass<1, 1, 1>, px, (long long)n3, nullptr, t2, e3, pass)) != TOPAY_OK) return s;
-    // 2-D: along y (lines x), along x (lines y) — grid_map.cpp:125-207
+  }
+  // One signed 2-D field from an occupancy grid: along y (lines x), along x (lines y), positive then negative part —
+  // grid_map.cpp:125-207 and, with other seeds, 211-279, 283-351, 355-423
+  auto field2d = [&](const signed char* occ, double* out) -> topay_status {
     EdtPass qy{(long long)nx, ny, (long long)nx, 0, (long long)ny, 1, 0, 0};
     EdtPass qx{(long long)ny, nx, (long long)ny, 0, 1, (long long)ny, 0, 0};
-    if ((s = launch(k_edt_pass<0, 0, 0>, k_edt_pass<0, 0, 1>, qy, (long long)n2, d_occ2, nullptr, t1, pass)) != TOPAY_OK) return s;
-    if ((s = launch(k_edt_pass<1, 1, 0>, k_edt_pass<1, 1, 1>, qx, (long long)n2, nullptr, t1, e2, pass)) != TOPAY_OK) return s;
+    for (int pass = 0; pass < 2; pass++) {
+      topay_status s2;
+      if ((s2 = launch(k_edt_pass<0, 0, 0>, k_edt_pass<0, 0, 1>, qy, (long long)n2, occ, nullptr, t1, pass)) != TOPAY_OK) return s2;
+      if ((s2 = launch(k_edt_pass<1, 1, 0>, k_edt_pass<1, 1, 1>, qx, (long long)n2, nullptr, t1, out, pass)) != TOPAY_OK) return s2;
+    }
+    return TOPAY_OK;
+  };
+  auto threshold = [&](const double* field, signed char* occ) {
+    const long long n = (long long)(M * n2);
+    hipLaunchKernelGGL(k_edt_threshold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, field, c->dp.chassis_colli_radius, occ, n);
+  };
+  if ((s = field2d(d_occ2, e2)) != TOPAY_OK) return s;              // esdf_buffer_2d
+  threshold(e2, d_occ2t);
+  if ((s = field2d(d_occ2t, e2i)) != TOPAY_OK) return s;            // esdf_buffer_2d_inflate (355-423)
+  if (!occ2d_critical) {
+    const long long n = (long long)(M * n2);
+    hipLaunchKernelGGL(k_edt_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const signed char*)d_occ3, d_occ2c,
+                       (long long)n2, nz, (long long)M);
   }
+  if ((s = field2d(d_occ2c, e2s)) != TOPAY_OK) return s;            // 2-D critical (211-279)
+  threshold(e2s, d_occ2t);
+  if ((s = field2d(d_occ2t, e2c)) != TOPAY_OK) return s;            // critical inflate, stored in esdf_buffer_2d_critical (283-351)
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   // into the map slots (device to device), descriptors as topay_set_map
@@ -937,7 +970,11 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
     const int map_id = first_map_id + k;
     if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
     if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
+    if ((s = c->map2d_inf[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
+    if ((s = c->map2d_crit[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
     HIPCHK(hipMemcpyAsync(c->map2d[map_id].p, e2 + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->map2d_inf[map_id].p, e2i + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->map2d_crit[map_id].p, e2c + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->map3d[map_id].p, e3 + (size_t)k * n3, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
     DevMap& m = c->hmaps[map_id];
     for (int i = 0; i < 3; i++) {
@@ -948,6 +985,8 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
     m.res_inv = 1.0 / desc->resolution;
     m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
     m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
+    m.esdf2d_inflate = (glb_cdp)c->map2d_inf[map_id].as<double>();
+    m.esdf2d_critical = (glb_cdp)c->map2d_crit[map_id].as<double>();
     c->have_map[map_id] = 1;
   }
   HIPCHK(hipMemcpyAsync((char*)c->dmaps.p + sizeof(DevMap) * first_map_id, &c->hmaps[first_map_id], sizeof(DevMap) * n_maps,
@@ -963,9 +1002,26 @@ topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, 
   return TOPAY_OK;
 }
 
+topay_status topay_build_esdf_batch(topay_ctx* c, int n_maps, int first_map_id, const topay_map_desc_t* desc,
+                                    const signed char* occ2d, const signed char* occ3d) {
+  return topay_build_esdf_fields(c, n_maps, first_map_id, desc, occ2d, nullptr, occ3d);
+}
+
 topay_status topay_build_esdf(topay_ctx* c, int map_id, const topay_map_desc_t* desc, const signed char* occ2d,
                               const signed char* occ3d) {
-  return topay_build_esdf_batch(c, 1, map_id, desc, occ2d, occ3d);
+  return topay_build_esdf_fields(c, 1, map_id, desc, occ2d, nullptr, occ3d);
+}
+
+// The two front-end fields of a map built on the device (GridMap::esdf_buffer_2d_inflate, esdf_buffer_2d_critical).
+topay_status topay_get_map_fields(topay_ctx* c, int map_id, double* esdf2d_inflate, double* esdf2d_critical) {
+  if (!c || map_id < 0 || map_id >= TOPAY_MAX_MAPS || !c->have_map[map_id]) return TOPAY_ERR_NO_MAP;
+  if (!c->map2d_inf[map_id].p || !c->map2d_crit[map_id].p) { set_err("map slot was not built by topay_build_esdf*"); return TOPAY_ERR_NO_MAP; }
+  HIPCHK(hipSetDevice(c->device));
+  const DevMap& m = c->hmaps[map_id];
+  const size_t n2 = (size_t)m.dims[0] * m.dims[1];
+  if (esdf2d_inflate) HIPCHK(memcpy_sync(c, esdf2d_inflate, c->map2d_inf[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf2d_critical) HIPCHK(memcpy_sync(c, esdf2d_critical, c->map2d_crit[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
 }
 
 // Copy a resident map back (tests, or a caller that wants the GPU-built ESDF on the host); milliseconds of the last build.

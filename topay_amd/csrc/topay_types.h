@@ -38,6 +38,8 @@ struct DevMap {
   int pad;
   glb_cdp esdf2d;
   glb_cdp esdf3d;
+  glb_cdp esdf2d_inflate;    // GridMap::esdf_buffer_2d_inflate / esdf_buffer_2d_critical (front-end fields; null when the
+  glb_cdp esdf2d_critical;   // map came through topay_set_map without them)
 };
 
 struct DevLbfgs {
