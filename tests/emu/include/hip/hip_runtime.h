@@ -231,6 +231,7 @@ inline double __hiloint2double(int hi, int lo) {
 }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }

@@ -107,6 +107,113 @@ __global__ void k_edt_pass(EdtPass P, const signed char* occ, const double* src,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same 1-D pass for lines of up to 512 cells, by exhaustive search instead of the serial envelope construction.
+// Every squared distance of the construction is an integer (or "no seed"), so the lower envelope's value at q is
+// exactly  min over v of (q - v)^2 + f(v),  and that minimum can be taken directly: one thread per OUTPUT cell walks
+// outwards from q and stops as soon as r^2 alone is no better than what it has (r^2 >= best).  Near obstacles that is
+// a handful of steps; the work is 10-30 integer operations per cell instead of ~10 dependent memory round trips per
+// cell, it is the same for every lane of a wave (neighbouring cells have neighbouring distances), and every access is
+// coalesced.  32-bit integers, "no seed" = 2^30 (r^2 <= 2^18 cannot overflow it); results are the reference's bit for bit
+// (tests/test_edt.py).  k_edt_direct: lines along the contiguous axis, neighbours straight from global memory (the reads
+// of a wave overlap: L1).  k_edt_tile: strided lines; a tile of W memory-adjacent lines x n cells is staged in LDS
+// ([n][W], conflict-free), so HBM sees one read and one write per cell and pass.
+// ---------------------------------------------------------------------------------------------------------------
+#define TOPAY_EDT_INF (1 << 30)
+
+// SRC 0: occupancy bytes ; SRC 1: int32 squared distances.  FIN as in k_edt_pass (FIN 0 stores int32).
+template <int SRC, int FIN>
+__device__ __forceinline__ void edt_store(int best, long long a, int* dst_i, double* dst_d, int pass, double res) {
+  if (FIN == 0) {
+    dst_i[a] = best;
+  } else {
+    const double val = best >= TOPAY_EDT_INF ? TOPAY_EDT_DMAX : (double)best;
+    const double dd = res * sqrt(val);
+    if (pass == 0) dst_d[a] = dd;
+    else if (dd > 0.0) dst_d[a] += (-dd + res);
+  }
+}
+
+template <int SRC, int FIN>
+__global__ void k_edt_direct(long long n_elems, int n, long long map_stride, const signed char* occ, const int* src, int* dst_i,
+                             double* dst_d, int pass, double res) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // cell within the map, lines are [k n, (k + 1) n)
+  if (e >= n_elems) return;
+  const long long mo = (long long)blockIdx.y * map_stride;
+  const int q = (int)((unsigned)e % (unsigned)n);   // (a map of lines <= 512 cells has fewer than 2^31 cells: 32-bit division)
+  auto f = [&](long long a) -> int {
+    if (SRC == 0) return ((occ[mo + a] == 1) == (pass == 0)) ? 0 : TOPAY_EDT_INF;
+    return src[mo + a];
+  };
+  int best = f(e);
+  for (int r = 1; r < n; r++) {
+    const int rr = r * r;
+    if (rr >= best) break;
+    const bool lo = q - r >= 0, hi = q + r < n;
+    if (!lo && !hi) break;
+    if (lo) { const int t = rr + f(e - r); best = t < best ? t : best; }
+    if (hi) { const int t = rr + f(e + r); best = t < best ? t : best; }
+  }
+  edt_store<SRC, FIN>(best, mo + e, dst_i, dst_d, pass, res);
+}
+
+// First pass along the contiguous axis when the lines are 16, 32 or 64 cells long (the benchmark map's z axis: 16): the
+// input is binary, so the squared distance along the line is the square of the distance to the nearest seed, and a
+// line is a bit field of the wave's ballot -- the nearest seed below / above cell q is a count-leading / trailing-zeros
+// on the line's bits.  One thread per cell, no loop, loads and stores in memory order.
+template <int N>
+__global__ void k_edt_first_ballot(long long n_elems, long long map_stride, const signed char* occ, int* dst_i, int pass) {
+  static_assert(N == 16 || N == 32 || N == 64, "line length must divide the wave");
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long mo = (long long)blockIdx.y * map_stride;
+  const bool live = e < n_elems;
+  const bool seed = live && ((occ[mo + (live ? e : 0)] == 1) == (pass == 0));
+  const unsigned long long all = __ballot(seed);
+  const int lane = threadIdx.x & 63, q = lane & (N - 1);
+  const unsigned long long line = N == 64 ? all : ((all >> (lane - q)) & ((1ull << N) - 1ull));
+  const unsigned long long below = line & ((q == 63) ? ~0ull : ((2ull << q) - 1ull));   // seeds at cells <= q
+  const unsigned long long above = line >> q;                                             // seeds at cells >= q, shifted to bit 0
+  int d = TOPAY_EDT_INF;
+  if (below) d = q - (63 - __clzll((long long)below));
+  if (above) { const int u = __ffsll((long long)above) - 1; d = u < d ? u : d; }
+  if (live) dst_i[mo + e] = d >= TOPAY_EDT_INF ? TOPAY_EDT_INF : d * d;
+}
+
+// Tile t of a map: W lines whose cells q sit at  tile_base(t) + q * step + l,  l < W  (W contiguous cells), n cells each.
+// tiles are numbered so that tile_base = (t / inner_tiles) * outer_stride + (t % inner_tiles) * W.
+template <int SRC, int FIN>
+__global__ void k_edt_tile(int n, int W, long long step, long long inner_tiles, long long outer_stride, long long map_stride,
+                           const signed char* occ, const int* src, int* dst_i, double* dst_d, int pass, double res) {
+  int* tile = (int*)TOPAY_EDT_LDS;   // [n][W]
+  const long long t = blockIdx.x;
+  const long long base = (long long)blockIdx.y * map_stride + (t / inner_tiles) * outer_stride + (t % inner_tiles) * W;
+  const int cells = n * W;
+  // (q, l) of cell c = threadIdx.x + k blockDim.x, advanced without a division per cell
+  const int q0 = (int)threadIdx.x / W, l0 = (int)threadIdx.x - q0 * W, dq = (int)blockDim.x / W, dl = (int)blockDim.x - dq * W;
+  int q = q0, l = l0;
+  for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+    const long long a = base + (long long)q * step + l;
+    tile[c] = SRC == 0 ? ((((occ[a] == 1) == (pass == 0)) ? 0 : TOPAY_EDT_INF)) : src[a];
+    q += dq; l += dl;
+    if (l >= W) { l -= W; q++; }
+  }
+  __syncthreads();
+  q = q0; l = l0;
+  for (int c = threadIdx.x; c < cells; c += blockDim.x, q += dq, l += dl) {
+    if (l >= W) { l -= W; q++; }
+    int best = tile[c];
+    for (int r = 1; r < n; r++) {
+      const int rr = r * r;
+      if (rr >= best) break;
+      const bool lo = q - r >= 0, hi = q + r < n;
+      if (!lo && !hi) break;
+      if (lo) { const int v = rr + tile[c - r * W]; best = v < best ? v : best; }
+      if (hi) { const int v = rr + tile[c + r * W]; best = v < best ? v : best; }
+    }
+    edt_store<SRC, FIN>(best, base + (long long)q * step + l, dst_i, dst_d, pass, res);
+  }
+}
+
 // Seeds of the "inflate" fields (grid_map.cpp:283-300, 355-372): a cell is occupied when the field it is derived from
 // is below the chassis radius there.
 __global__ void k_edt_threshold(const double* field, double thr, signed char* occ, long long n) {

@@ -521,6 +521,10 @@ struct topay_ctx {
   std::vector<DevMap> hmaps = std::vector<DevMap>(TOPAY_MAX_MAPS);
   std::vector<DevBuf> map2d = std::vector<DevBuf>(TOPAY_MAX_MAPS), map3d = std::vector<DevBuf>(TOPAY_MAX_MAPS);
   std::vector<DevBuf> map2d_inf = std::vector<DevBuf>(TOPAY_MAX_MAPS), map2d_crit = std::vector<DevBuf>(TOPAY_MAX_MAPS);
+  // Maps built on the device as a batch live in one arena per build call (the construction writes the fields where
+  // they stay; the slots' descriptors point into it), kept until the context is destroyed.
+  struct MapArena { DevBuf buf; int first = 0, n = 0; };
+  std::vector<MapArena> map_arenas;
   DevBuf dmaps;
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
   // batch
@@ -767,6 +771,7 @@ void topay_destroy(topay_ctx* c) {
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); c->map2d_inf[i].release(); c->map2d_crit[i].release(); }
+  for (auto& a : c->map_arenas) a.buf.release();
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     if (c->bevent[k]) (void)hipEventDestroy(c->bevent[k]);
     if (c->bstream[k] && c->bstream[k] != c->stream) (void)hipStreamDestroy(c->bstream[k]);
@@ -882,8 +887,20 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   if ((s = c->edt_occ.ensure(M * (n3 + 3 * n2))) != TOPAY_OK) return s;   // 3-D, 2-D, 2-D critical, 2-D scratch
   if ((s = c->edt_tmp1.ensure(M * n3 * 8)) != TOPAY_OK) return s;
   if ((s = c->edt_tmp2.ensure(M * n3 * 8)) != TOPAY_OK) return s;
-  if ((s = c->edt_out3.ensure(M * n3 * 8)) != TOPAY_OK) return s;
-  if ((s = c->edt_out2.ensure(M * n2 * 8 * 4)) != TOPAY_OK) return s;   // plain, inflate, critical, scratch
+  // results: e3 | e2 | e2 inflate | e2 critical in a new arena (they stay there); the plain critical field is scratch
+  // (a rebuild of the same range of slots -- a new episode's maps -- takes the arena of the previous build over)
+  topay_ctx::MapArena* ar = nullptr;
+  for (auto& a : c->map_arenas)
+    if (a.first == first_map_id && a.n == n_maps) ar = &a;
+  if (!ar) {
+    c->map_arenas.emplace_back();
+    ar = &c->map_arenas.back();
+    ar->first = first_map_id;
+    ar->n = n_maps;
+  }
+  DevBuf& arena = ar->buf;
+  if ((s = arena.ensure(M * (n3 + 3 * n2) * 8)) != TOPAY_OK) return s;
+  if ((s = c->edt_out2.ensure(M * n2 * 8)) != TOPAY_OK) return s;
   // workspace for the envelope stacks of the pass with the most (lines x cells), per map
   const size_t ws_elems = std::max(std::max((size_t)nx * ny * (nz + 2), (size_t)nx * nz * (ny + 2)), (size_t)ny * nz * (nx + 2));
   if ((s = c->edt_v.ensure(M * ws_elems * 4)) != TOPAY_OK) return s;
@@ -898,11 +915,11 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   HIPCHK(hipEventRecord(c->ev0, c->stream));
   double* t1 = c->edt_tmp1.as<double>();
   double* t2 = c->edt_tmp2.as<double>();
-  double* e3 = c->edt_out3.as<double>();
-  double* e2 = c->edt_out2.as<double>();
+  double* e3 = arena.as<double>();
+  double* e2 = e3 + M * n3;
   double* e2i = e2 + M * n2;       // inflate
   double* e2c = e2i + M * n2;      // critical (holds the critical-inflate field at the end, as the reference's buffer does)
-  double* e2s = e2c + M * n2;      // scratch: the plain critical field
+  double* e2s = c->edt_out2.as<double>();   // scratch: the plain critical field
   int* vws = c->edt_v.as<int>();
   double* zws = c->edt_z.as<double>();
   const double res = desc->resolution;
@@ -927,7 +944,42 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
     }
     return TOPAY_OK;
   };
-  for (int pass = 0; pass < 2; pass++) {
+  // Lines of up to 512 cells (every benchmark map: 200 x 200 x 16) take the exhaustive-search passes (topay_edt.h:
+  // k_edt_direct / k_edt_tile, 32-bit squared distances between the passes); longer lines the serial envelope passes.
+  const bool small_lines = std::max(nx, std::max(ny, nz)) <= 512 && getenv("TOPAY_EDT_ENVELOPE") == nullptr;
+  auto pick_w = [](long long lines) { int w = 1; for (int d = 1; d <= 64; d++) if (lines % d == 0) w = d; return w; };
+  int* i1 = (int*)t1;
+  int* i2 = (int*)t2;
+  auto direct = [&](auto kern, long long n_elems, int n, const signed char* occ, const int* src, int* dst_i, double* dst_d, int pass) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_elems + 255) / 256), (unsigned)n_maps), dim3(256), 0, c->stream, n_elems, n, n_elems, occ, src,
+                       dst_i, dst_d, pass, res);
+  };
+  auto tile = [&](auto kern, long long n_elems, int n, int W, long long step, long long inner_tiles, long long outer_stride, long long tiles,
+                  const int* src, int* dst_i, double* dst_d, int pass) -> topay_status {
+    const size_t lb = (size_t)n * W * sizeof(int);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)n_maps), dim3(256), lb, c->stream, n, W, step, inner_tiles, outer_stride, n_elems,
+                       (const signed char*)nullptr, src, dst_i, dst_d, pass, res);
+    return TOPAY_OK;
+  };
+  if (small_lines) {
+    // (tiles of up to 512 x 64 cells x 4 B = 128 KB of LDS: above the 64 KB default; set once, not per launch)
+    static std::once_flag edt_attr_once[16];
+    std::call_once(edt_attr_once[c->device % 16], [] {
+      (void)hipFuncSetAttribute((const void*)k_edt_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)k_edt_tile<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 4);
+    });
+    const int wy = pick_w(nz), wx = pick_w((long long)ny * nz);
+    for (int pass = 0; pass < 2; pass++) {   // 3-D: along z, y, x — grid_map.cpp:425-521
+      const dim3 g1((unsigned)((n3 + 255) / 256), (unsigned)n_maps);
+      if (nz == 16) hipLaunchKernelGGL(k_edt_first_ballot<16>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
+      else if (nz == 32) hipLaunchKernelGGL(k_edt_first_ballot<32>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
+      else if (nz == 64) hipLaunchKernelGGL(k_edt_first_ballot<64>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
+      else direct(k_edt_direct<0, 0>, (long long)n3, nz, d_occ3, nullptr, i1, nullptr, pass);
+      if ((s = tile(k_edt_tile<1, 0>, (long long)n3, ny, wy, nz, nz / wy, (long long)ny * nz, (long long)nx * (nz / wy), i1, i2, nullptr, pass)) != TOPAY_OK) return s;
+      if ((s = tile(k_edt_tile<1, 1>, (long long)n3, nx, wx, (long long)ny * nz, ((long long)ny * nz) / wx, 0, ((long long)ny * nz) / wx, i2, nullptr, e3, pass)) != TOPAY_OK) return s;
+    }
+  }
+  for (int pass = 0; pass < 2 && !small_lines; pass++) {
     // 3-D: along z (lines (x, y)), along y (lines (x, z)), along x (lines (y, z)) — grid_map.cpp:425-521
     EdtPass pz{(long long)nx * ny, nz, (long long)nx * ny, 0, (long long)nz, 1, 0, 0};
     EdtPass py{(long long)nx * nz, ny, (long long)nz, (long long)ny * nz, 1, (long long)nz, 0, 0};
@@ -939,6 +991,15 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   // One signed 2-D field from an occupancy grid: along y (lines x), along x (lines y), positive then negative part —
   // grid_map.cpp:125-207 and, with other seeds, 211-279, 283-351, 355-423
   auto field2d = [&](const signed char* occ, double* out) -> topay_status {
+    if (small_lines) {
+      const int w2 = pick_w(ny);
+      for (int pass = 0; pass < 2; pass++) {
+        topay_status s2;
+        direct(k_edt_direct<0, 0>, (long long)n2, ny, occ, nullptr, i1, nullptr, pass);
+        if ((s2 = tile(k_edt_tile<1, 1>, (long long)n2, nx, w2, ny, ny / w2, 0, ny / w2, i1, nullptr, out, pass)) != TOPAY_OK) return s2;
+      }
+      return TOPAY_OK;
+    }
     EdtPass qy{(long long)nx, ny, (long long)nx, 0, (long long)ny, 1, 0, 0};
     EdtPass qx{(long long)ny, nx, (long long)ny, 0, 1, (long long)ny, 0, 0};
     for (int pass = 0; pass < 2; pass++) {
@@ -965,17 +1026,10 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   if ((s = field2d(d_occ2t, e2c)) != TOPAY_OK) return s;            // critical inflate, stored in esdf_buffer_2d_critical (283-351)
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev1, c->stream));
-  // into the map slots (device to device), descriptors as topay_set_map
+  // the map slots point into the arena; descriptors as topay_set_map
   for (int k = 0; k < n_maps; k++) {
     const int map_id = first_map_id + k;
-    if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
-    if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
-    if ((s = c->map2d_inf[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
-    if ((s = c->map2d_crit[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
-    HIPCHK(hipMemcpyAsync(c->map2d[map_id].p, e2 + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->map2d_inf[map_id].p, e2i + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->map2d_crit[map_id].p, e2c + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->map3d[map_id].p, e3 + (size_t)k * n3, n3 * 8, hipMemcpyDeviceToDevice, c->stream));
+    c->map2d[map_id].release(); c->map3d[map_id].release(); c->map2d_inf[map_id].release(); c->map2d_crit[map_id].release();
     DevMap& m = c->hmaps[map_id];
     for (int i = 0; i < 3; i++) {
       m.origin[i] = desc->origin[i]; m.dims[i] = desc->dims[i];
@@ -983,10 +1037,10 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
     }
     m.res = desc->resolution;
     m.res_inv = 1.0 / desc->resolution;
-    m.esdf2d = (glb_cdp)c->map2d[map_id].as<double>();
-    m.esdf3d = (glb_cdp)c->map3d[map_id].as<double>();
-    m.esdf2d_inflate = (glb_cdp)c->map2d_inf[map_id].as<double>();
-    m.esdf2d_critical = (glb_cdp)c->map2d_crit[map_id].as<double>();
+    m.esdf2d = (glb_cdp)(e2 + (size_t)k * n2);
+    m.esdf3d = (glb_cdp)(e3 + (size_t)k * n3);
+    m.esdf2d_inflate = (glb_cdp)(e2i + (size_t)k * n2);
+    m.esdf2d_critical = (glb_cdp)(e2c + (size_t)k * n2);
     c->have_map[map_id] = 1;
   }
   HIPCHK(hipMemcpyAsync((char*)c->dmaps.p + sizeof(DevMap) * first_map_id, &c->hmaps[first_map_id], sizeof(DevMap) * n_maps,
@@ -997,7 +1051,7 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   c->last_edt_ms = ms;
   // the construction's workspace (occupancy, two intermediate volumes, the envelope stacks, the staged results: about
   // five times the maps themselves) is not needed once the fields sit in their map slots
-  DevBuf* ws[] = {&c->edt_occ, &c->edt_tmp1, &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3};
+  DevBuf* ws[] = {&c->edt_occ, &c->edt_tmp1, &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2};
   for (DevBuf* b : ws) b->release();
   return TOPAY_OK;
 }
@@ -1015,12 +1069,12 @@ topay_status topay_build_esdf(topay_ctx* c, int map_id, const topay_map_desc_t* 
 // The two front-end fields of a map built on the device (GridMap::esdf_buffer_2d_inflate, esdf_buffer_2d_critical).
 topay_status topay_get_map_fields(topay_ctx* c, int map_id, double* esdf2d_inflate, double* esdf2d_critical) {
   if (!c || map_id < 0 || map_id >= TOPAY_MAX_MAPS || !c->have_map[map_id]) return TOPAY_ERR_NO_MAP;
-  if (!c->map2d_inf[map_id].p || !c->map2d_crit[map_id].p) { set_err("map slot was not built by topay_build_esdf*"); return TOPAY_ERR_NO_MAP; }
-  HIPCHK(hipSetDevice(c->device));
   const DevMap& m = c->hmaps[map_id];
+  if (!m.esdf2d_inflate || !m.esdf2d_critical) { set_err("map slot was not built by topay_build_esdf*"); return TOPAY_ERR_NO_MAP; }
+  HIPCHK(hipSetDevice(c->device));
   const size_t n2 = (size_t)m.dims[0] * m.dims[1];
-  if (esdf2d_inflate) HIPCHK(memcpy_sync(c, esdf2d_inflate, c->map2d_inf[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
-  if (esdf2d_critical) HIPCHK(memcpy_sync(c, esdf2d_critical, c->map2d_crit[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf2d_inflate) HIPCHK(memcpy_sync(c, esdf2d_inflate, (const void*)m.esdf2d_inflate, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf2d_critical) HIPCHK(memcpy_sync(c, esdf2d_critical, (const void*)m.esdf2d_critical, n2 * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1030,8 +1084,8 @@ topay_status topay_get_map(topay_ctx* c, int map_id, double* esdf2d, double* esd
   HIPCHK(hipSetDevice(c->device));
   const DevMap& m = c->hmaps[map_id];
   const size_t n2 = (size_t)m.dims[0] * m.dims[1], n3 = n2 * m.dims[2];
-  if (esdf2d) HIPCHK(memcpy_sync(c, esdf2d, c->map2d[map_id].p, n2 * 8, hipMemcpyDeviceToHost));
-  if (esdf3d) HIPCHK(memcpy_sync(c, esdf3d, c->map3d[map_id].p, n3 * 8, hipMemcpyDeviceToHost));
+  if (esdf2d) HIPCHK(memcpy_sync(c, esdf2d, (const void*)m.esdf2d, n2 * 8, hipMemcpyDeviceToHost));
+  if (esdf3d) HIPCHK(memcpy_sync(c, esdf3d, (const void*)m.esdf3d, n3 * 8, hipMemcpyDeviceToHost));
   if (build_ms) *build_ms = c->last_edt_ms;
   return TOPAY_OK;
 }
