@@ -676,6 +676,7 @@ struct World {
       generateCuboidCase(mp, rng, cloud);
     }
     gm.fillOccupancy(cloud);
+    if (nthreads < 0) return;   // occupancy only (the caller builds the distance fields on the device)
     gm.updateESDF2d();
     gm.updateESDF3d(nthreads);
   }

@@ -90,7 +90,8 @@ class World:
         self.dims, self.origin, self.res, self.min_b, self.max_b = dims, origin, r.value, mn, mx
         n2 = int(dims[0]) * int(dims[1])
         n3 = n2 * int(dims[2])
-        self.esdf2d = np.ctypeslib.as_array(L.wl_world_esdf2d(self.h), shape=(n2,))
+        # nthreads < 0: occupancy grids only (no CPU distance fields; scenario sampling and init paths need them)
+        self.esdf2d = np.ctypeslib.as_array(L.wl_world_esdf2d(self.h), shape=(n2,)) if nthreads >= 0 or _borrowed is not None else None
         # None when the batch generator was told to drop it (TablesBatch(keep_esdf3d=...))
         self.esdf3d = np.ctypeslib.as_array(L.wl_world_esdf3d(self.h), shape=(n3,)) if L.wl_world_esdf3d_size(self.h) == n3 else None
         self.occ2d = np.ctypeslib.as_array(L.wl_world_occ2d(self.h), shape=(n2,))

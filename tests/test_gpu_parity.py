@@ -711,3 +711,43 @@ def test_rccl_record_gather_on_one_gpu():
     g = out["config"]["record_gather"]
     assert g is not None and g["gathers"] >= 4 and g["own_rows_match"] is True and g["rows"] == 64 == g["rows_expected"]
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["n_not_launched"] == 0
+
+
+@pytest.mark.gpu
+def test_config5_full_size_field_evaluation_parity():
+    """BASELINE configs[4] at FULL size: 50 x 50 x 1.6 m at 0.02 m = 2500 x 2500 x 80 cells, a 4.0 GB 3-D field whose
+    byte offsets pass 2^31 and 2^32.  The occupancy comes from the harness, the fields are built on the device (the
+    serial-envelope passes: lines of 2500 cells) and copied back for the oracle, which then evaluates the same x on the
+    same buffers: per-evaluation parity at the far corner of the map, where the offsets are largest."""
+    w = wl.World(wl.CUBOIDS, seed=42, size_xy=50.0, size_z=1.6, res=0.02, cloud_res=0.02, nthreads=-1)
+    assert tuple(w.dims) == (2500, 2500, 80)
+    opt = api.MomaTrajOptBatch(device=0)
+    opt.build_esdf(w.origin, w.res, w.dims, w.min_b, w.max_b, w.occ2d, w.occ3d)
+    e2, e3, ms = opt.get_map()
+    assert e3.nbytes == 4_000_000_000 and np.isfinite(e3[::100003]).all() and (e3[::100003] < 50.0).all()
+    m = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, e2, e3)
+    rng = np.random.default_rng(8)
+    paths = []
+    for corner in ((21.0, 21.0), (-22.0, 20.0), (18.0, -23.0)):        # x = 21 m: cell 2300 of 2500, offset ~3.7e9 B
+        a = np.array(corner)
+        ang = rng.uniform(-np.pi, np.pi)
+        g = np.clip(a + 5.0 * np.array([np.cos(ang), np.sin(ang)]), -23.5, 23.5)
+        t = np.linspace(0, 1, 9)[:, None]
+        q0, q1 = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+        paths.append(np.concatenate([a + t * (g - a), np.full((9, 1), np.arctan2(*(g - a)[::-1])), q0 + t * (q1 - q0)], axis=1))
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    opt.set_init_traj(lens, np.concatenate(paths))
+    o = orc.Oracle(m)
+    for b, p in enumerate(paths):
+        n = o.set_init_traj(p)
+        assert np.allclose(opt.get_x(b), o.get_x(), rtol=0, atol=1e-12)
+        for trial in range(2):
+            x = o.get_x() + (0.05 * rng.standard_normal(n) if trial else 0.0)
+            o.set_alm([0.2, -0.1], [1e4, 2e4])
+            f, g = o.eval(2, x)
+            fg, gg, _ = opt.eval(2, b, x, [0.2, -0.1], [1e4, 2e4])
+            assert abs(f - fg) <= 1e-11 * abs(f) and np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
+    ok = opt.optimize()
+    assert np.isfinite(opt.traj_cost[ok]).all()
+    print(f"4 GB field built on the device in {ms:.0f} ms")
+    w.close()

@@ -26,7 +26,7 @@ rec = []
 t0 = time.perf_counter()
 def fin(i):
     o = opts[i % depth]; o.finish()
-    rec.append((i, o.start_us()[m].copy(), o.elapsed_us()[m].copy(), time.perf_counter() - t0, o.hw_ids()[m].copy()))
+    rec.append((i, o.start_us(raw=True)[m].copy(), o.elapsed_us()[m].copy(), time.perf_counter() - t0, o.hw_ids()[m].copy()))
 host = []
 for i in range(steps):
     o = opts[i % depth]
@@ -44,7 +44,7 @@ for (i, s, u, th, hw_) in rec:
     print(f"  batch {i}: first start {s.min()/1e3:.0f}, median start {np.median(s)/1e3:.0f}, last start {s.max()/1e3:.0f}, last end {(s+u).max()/1e3:.0f} (host saw finish at {th*1e3:.0f})")
 Nm = N[m]
 cls = np.where(Nm <= 10, 0, np.where(Nm <= 21, 1, np.where(Nm <= 32, 2, np.where(Nm <= 42, 3, 4))))
-for (i, s_, u_, th, hw_) in rec[:6]:
+for (i, s_, u_, th, hw_) in rec[:8]:
     s0 = s_ - base
     print(f"  batch {i} per class (first start, queue drained = last start, last end) ms:",
           [(int(s0[cls == k].min() / 1e3), int(s0[cls == k].max() / 1e3), int((s0 + u_)[cls == k].max() / 1e3)) for k in range(5)])

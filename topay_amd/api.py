@@ -373,10 +373,12 @@ class MomaTrajOptBatch:
         _chk(self.L, self.L.topay_get_elapsed_us(self.h, _dp(t), None, None))
         return t
 
-    def start_us(self):
+    def start_us(self, raw=False):
+        """When every candidate's solve began, on the device's constant clock (raw=True: comparable between contexts of
+        one device; default: relative to the first start of this batch)."""
         t = np.zeros(self.batch)
         _chk(self.L, self.L.topay_get_elapsed_us(self.h, None, _dp(t), None))
-        return t - t.min()
+        return t if raw else t - t.min()
 
     def hw_ids(self):
         h = np.zeros(self.batch, dtype=np.int32)
