@@ -734,10 +734,10 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     // A few slots are left to everything that is not a solve: the init kernel, the feasibility gate and the result
     // gather of the OTHER batches in flight, the runtime's copy kernels, a collective.  Resident solver waves own their
     // SIMD's whole register file, so on a device they fill completely such a kernel waits until workgroups exit --
-    // with chained batches, for ever.  TOPAY_RESERVE_SLOTS overrides (0: use every slot).
+    // with chained batches, for ever.  TOPAY_RESERVE_SLOTS=<n> keeps n slots free (default 0: use every slot).
     {
       const char* rs = getenv("TOPAY_RESERVE_SLOTS");
-      const int reserve = rs ? atoi(rs) : 16;
+      const int reserve = rs ? atoi(rs) : 0;   // (measured: no gain from a standing reserve with two batches in flight)
       if (reserve > 0 && reserve < c->simd_slots / 2) c->simd_slots -= reserve;
     }
   }
