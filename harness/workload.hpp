@@ -603,7 +603,9 @@ inline void normalizeAngle(double ref, double& a) {
   while (ref - a < -M_PI) a -= 2 * M_PI;
 }
 
-// graph_search.cpp:119-176
+// graph_search.cpp:119-176.  (No fused multiply-adds here: this restatement is also the checker of the device's
+// topay_dense_path, and the reference's build has none either.)
+__attribute__((optimize("fp-contract=off")))
 inline std::vector<std::array<double, 4>> getDensePath(const std::vector<std::array<double, 2>>& raw, double step_size,
                                                        double start_yaw, double end_yaw, double v_max, double w_max) {
   std::vector<std::array<double, 2>> dense;

@@ -250,3 +250,15 @@ def front_end_fields(occ2d, occ3d, dims, res, chassis_radius=0.4, occ2d_critical
     L.wl_edt_front_end_fields(o2.ctypes.data_as(P8), None if oc is None else oc.ctypes.data_as(P8), o3.ctypes.data_as(P8), nx, ny, nz,
                               float(res), float(chassis_radius), inf.ctypes.data_as(c_dp), cr.ctypes.data_as(c_dp))
     return inf, cr
+
+
+def dense_path(raw_xy, start_yaw, end_yaw, step_size=1.414, v_max=1.0, w_max=1.25):
+    """CPU restatement of GraphSearch::getDensePath (graph_search.cpp:119-176) -> [m, 4] array (x, y, theta, dt)."""
+    L = lib()
+    raw = np.ascontiguousarray(raw_xy, dtype=np.float64).reshape(-1, 2)
+    cap = 4 * (int(np.ceil(np.linalg.norm(np.diff(raw, axis=0), axis=1) / step_size).clip(1).sum()) + 4)
+    out = np.zeros((cap, 4))
+    L.wl_dense_path.argtypes = [c_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_dp, C.c_int]
+    L.wl_dense_path.restype = C.c_int
+    n = L.wl_dense_path(raw.ctypes.data_as(c_dp), len(raw), step_size, start_yaw, end_yaw, v_max, w_max, out.ctypes.data_as(c_dp), cap)
+    return out[:n].copy()

@@ -89,6 +89,17 @@ void wl_edt(const char* occ2d, const char* occ3d, int nx, int ny, int nz, double
 }
 
 
+// GraphSearch::getDensePath restatement (checker of topay_dense_path): returns the number of entries, writes at most cap
+int wl_dense_path(const double* raw_xy, int n, double step_size, double start_yaw, double end_yaw, double v_max, double w_max, double* out,
+                  int cap) {
+  std::vector<std::array<double, 2>> raw((size_t)n);
+  for (int i = 0; i < n; i++) raw[i] = {raw_xy[2 * i], raw_xy[2 * i + 1]};
+  auto r = getDensePath(raw, step_size, start_yaw, end_yaw, v_max, w_max);
+  for (size_t i = 0; i < r.size() && (int)i < cap; i++)
+    for (int k = 0; k < 4; k++) out[4 * i + k] = r[i][k];
+  return (int)r.size();
+}
+
 // the two front-end fields of updateESDF from the occupancy grids (occ2d_critical may be null: projection of occ3d)
 void wl_edt_front_end_fields(const char* occ2d, const char* occ2d_critical, const char* occ3d, int nx, int ny, int nz, double res,
                              double chassis_radius, double* inflate, double* critical) {

@@ -248,6 +248,25 @@ topay_status topay_get_elapsed_us(topay_ctx* ctx, double* us /* batch */, double
  * it samples or interpolates (mcrrts.cpp, planner.cpp:529-548). */
 topay_status topay_whole_body_collision(topay_ctx* ctx, int map_id, int n, const double* states, int* collide);
 
+/* First slice of the front-end that produces optimizeTraj's init paths.
+ * topay_dense_path == GraphSearch::getDensePath (src/planner/src/graph_search.cpp:119-176) for n_paths raw 2-D paths:
+ *   raw_len[p] points of path p, raw_xy ragged (sum x 2); out[p][cap_per_path][4] = (x, y, theta, dt) of the entries the
+ *   reference keeps (dt > 1e-3, plus the final pose); out_len[p] = their number (entries beyond cap_per_path are counted,
+ *   not written).
+ * topay_connect_check_num / topay_connect_collision == MCRRTs::connectCollision (src/planner/include/planner/mcrrts.h:
+ *   310-348) for n_edges edges of the joint-space tree.  The car poses along an edge come from OMPL's
+ *   ReedsSheppStateSpace (distance, interpolate: mcrrts.h:318-324, 336) -- a third-party dependency of the reference,
+ *   not part of it -- so the caller supplies rs_distance[e] and, for the piece_num[e] checks of edge e, the interpolated
+ *   car poses car_poses[sum piece_num][3] at fractions i / piece_num[e]; the library interpolates the joints, builds the
+ *   states and runs GridMap::isWholeBodyCollision on every one: collide[e] = 1 when any state of the edge collides. */
+topay_status topay_dense_path(topay_ctx* ctx, int n_paths, const int* raw_len, const double* raw_xy, double step_size,
+                              const double* start_yaw, const double* end_yaw, double v_max, double w_max, int cap_per_path,
+                              int* out_len, double* out);
+topay_status topay_connect_check_num(int n_edges, const double* rs_distance, const double* q_from /* n x 7 */,
+                                     const double* q_to /* n x 7 */, double check_res, int* piece_num);
+topay_status topay_connect_collision(topay_ctx* ctx, int map_id, int n_edges, const int* piece_num, const double* car_poses,
+                                     const double* q_from, const double* q_to, int* collide);
+
 /* MomaTraj playback of candidate i (moma_traj_opt.h:26-137): car_seq -- (x, y, theta, t) every 0.1 s from Simpson
  * panels of 0.025 s, what the reference stores in the trajectory object and publishes -- and getState(t) at caller-given
  * times, states[n_times][10] = (x, y, theta, q1..q7).  seq (seq_cap rows of 4 doubles) may be NULL; *n_seq receives the

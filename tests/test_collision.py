@@ -49,3 +49,79 @@ def test_whole_body_collision_on_gpu():
     st = _states(w, 2000, 3)
     assert (gpu.whole_body_collision(st) == emu.whole_body_collision(st)).all()   # bit-identical decisions
     w.close()
+
+
+def _raw_paths(rng, n):
+    """Raw 2-D paths as the graph search returns them: a few waypoints, some very short legs, a reversal."""
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(2, 7))
+        pts = np.cumsum(rng.uniform(-2.5, 2.5, (k, 2)), axis=0) + rng.uniform(-3, 3, 2)
+        if k > 3:
+            pts[2] = pts[1] + 1e-3 * rng.standard_normal(2)     # a degenerate (millimetre) leg
+        out.append(pts)
+    return out
+
+
+def _check_dense(opt, seed):
+    rng = np.random.default_rng(seed)
+    raws = _raw_paths(rng, 40)
+    sy = rng.uniform(-np.pi, np.pi, len(raws))
+    ey = rng.uniform(-np.pi, np.pi, len(raws))
+    got, n = opt.dense_path(raws, sy, ey)
+    for p, raw in enumerate(raws):
+        ref = wl.dense_path(raw, sy[p], ey[p])
+        assert n[p] == len(ref) == len(got[p])                    # same entries kept (dt > 1e-3), same count
+        assert (got[p][:, :2] == ref[:, :2]).all()                # positions: sqrt / division only, bit for bit
+        assert np.abs(got[p][:, 2:] - ref[:, 2:]).max() < 1e-14   # headings through atan2 (own implementation vs libm)
+    # a capacity that is too small is reported, not overrun
+    small, n2 = opt.dense_path(raws[:3], sy[:3], ey[:3], cap=2)
+    assert (n2 == n[:3]).all() and all(len(s) == 2 for s in small)
+
+
+def _check_connect(opt, w, seed):
+    """connectCollision for a batch of tree edges.  Reeds-Shepp geometry is OMPL's in the reference; the test stands in
+    a straight-line interpolation of the car pose for it (any interpolation does: it only produces the poses) and checks
+    the counts (mcrrts.h:321-328) and the verdicts against a per-state loop over the CPU isWholeBodyCollision."""
+    rng = np.random.default_rng(seed)
+    n = 60
+    qmax = np.array([3.1, 2.26, 3.1, 2.355, 3.1, 2.23, 6.28])
+    a = np.concatenate([rng.uniform(-8, 8, (n, 2)), rng.uniform(-np.pi, np.pi, (n, 1))], axis=1)
+    b = a + np.concatenate([rng.uniform(-1.5, 1.5, (n, 2)), rng.uniform(-0.5, 0.5, (n, 1))], axis=1)
+    qf = rng.uniform(-0.3, 0.3, (n, 7)) * qmax
+    qt = qf + rng.uniform(-0.4, 0.4, (n, 7))
+    dist = np.linalg.norm(b[:, :2] - a[:, :2], axis=1) + np.abs(b[:, 2] - a[:, 2])
+    res = 0.1
+    car = lambda e, fr: a[e] + fr[:, None] * (b[e] - a[e])
+    col, pn = opt.connect_collision(dist, car, qf, qt, res)
+    want_pn = np.maximum(np.maximum(np.ceil(dist / res), np.ceil(np.abs(qt - qf).max(axis=1) / res)), 3).astype(int)
+    assert (pn == want_pn).all()
+    ref = np.zeros(n, dtype=bool)
+    for e in range(n):
+        for i in range(pn[e]):
+            t = 1.0 * i / float(pn[e])
+            st = np.concatenate([a[e] + t * (b[e] - a[e]), qf[e] + (qt[e] - qf[e]) * t])
+            if w.collision(st):
+                ref[e] = True
+                break
+    assert 0.05 < ref.mean() < 0.95, "the sample must contain free and colliding edges"
+    assert (col == ref).all()
+
+
+def test_front_end_slice_kernel_sources_on_cpu():
+    w = wl.World(wl.CUBOIDS, seed=42)
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, w)
+    _check_dense(emu, 3)
+    _check_connect(emu, w, 4)
+    w.close()
+
+
+@pytest.mark.gpu
+def test_front_end_slice_on_gpu():
+    w = wl.World(wl.CUBOIDS, seed=42)
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, w)
+    _check_dense(opt, 5)
+    _check_connect(opt, w, 6)
+    w.close()

@@ -85,10 +85,13 @@ def test_eval_matches_oracle_and_emulator(gpu, emu, cuboids_small, stage):
             assert fg == fe and (gg == ge).all() and (eg == ee).all()  # bit-identical to the CPU execution
 
 
-def test_golden_fixture_evaluations(gpu):
+def test_golden_fixture_evaluations(cuboids_small):
     import os
 
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cuboids_seed42.npz"))
+    gpu = api.MomaTrajOptBatch(device=0)          # the fixture's own inputs (init paths as stored), the map from its seed
+    set_map(gpu, cuboids_small["world"])
+    gpu.set_init_traj(gold["lens"], gold["paths"])
     for b in range(len(gold["lens"])):
         for stage in (1, 2):
             f, g, _ = gpu.eval(stage, b, gold[f"x_{b}"], gold[f"lam_{b}"], gold[f"rho_{b}"])

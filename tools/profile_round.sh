@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): kernel trace + stats of the bench command, then separate PMC passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass), then the counter calibration.  Outputs under gpurun_out/prof_$1.
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT

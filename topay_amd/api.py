@@ -89,6 +89,9 @@ def load(path=None):
     L.topay_get_results.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_polytraj_msg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float),
                                          C.POINTER(C.c_float), C.POINTER(C.c_int8), c_ip]
+    L.topay_dense_path.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, C.c_double, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_ip, c_dp]
+    L.topay_connect_check_num.argtypes = [C.c_int, c_dp, c_dp, c_dp, C.c_double, c_ip]
+    L.topay_connect_collision.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
     L.topay_get_stats.argtypes = [C.c_void_p, c_ip]
     L.topay_get_alm.argtypes = [C.c_void_p, c_dp]
     L.topay_whole_body_collision.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_ip]
@@ -360,6 +363,34 @@ class MomaTrajOptBatch:
         out = np.zeros(len(st), dtype=np.int32)
         _chk(self.L, self.L.topay_whole_body_collision(self.h, map_id, len(st), _dp(st), _ip(out)))
         return out.astype(bool)
+
+    def dense_path(self, raw_paths, start_yaw, end_yaw, step_size=1.414, v_max=1.0, w_max=1.25, cap=None):
+        """GraphSearch::getDensePath for a list of raw 2-D paths ([k_p, 2] arrays) -> list of [m_p, 4] arrays (x, y, theta, dt)."""
+        lens = np.array([len(p) for p in raw_paths], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in raw_paths]))
+        sy = np.ascontiguousarray(start_yaw, dtype=np.float64)
+        ey = np.ascontiguousarray(end_yaw, dtype=np.float64)
+        if cap is None:
+            seg = [np.linalg.norm(np.diff(np.asarray(p, dtype=np.float64).reshape(-1, 2), axis=0), axis=1) for p in raw_paths]
+            cap = int(max(2 * (np.ceil(s_ / step_size).clip(1).sum() + 1) + 4 for s_ in seg))
+        out = np.zeros((len(lens), cap, 4))
+        n = np.zeros(len(lens), dtype=np.int32)
+        _chk(self.L, self.L.topay_dense_path(self.h, len(lens), _ip(lens), _dp(flat), step_size, _dp(sy), _dp(ey), v_max, w_max, cap, _ip(n), _dp(out)))
+        return [out[p, :min(n[p], cap)].copy() for p in range(len(lens))], n
+
+    def connect_collision(self, rs_distance, car_pose_fn, q_from, q_to, check_res, map_id=0):
+        """MCRRTs::connectCollision for a batch of edges.  car_pose_fn(e, fractions) -> [len(fractions), 3] car poses of
+        edge e (the caller's Reeds-Shepp interpolation).  Returns (collide[n] bool, piece_num[n])."""
+        rs = np.ascontiguousarray(rs_distance, dtype=np.float64)
+        qf = np.ascontiguousarray(q_from, dtype=np.float64).reshape(-1, 7)
+        qt = np.ascontiguousarray(q_to, dtype=np.float64).reshape(-1, 7)
+        n = len(rs)
+        pn = np.zeros(n, dtype=np.int32)
+        _chk(self.L, self.L.topay_connect_check_num(n, _dp(rs), _dp(qf), _dp(qt), check_res, _ip(pn)))
+        car = np.ascontiguousarray(np.concatenate([car_pose_fn(e, np.arange(pn[e]) / float(pn[e])) for e in range(n)]), dtype=np.float64)
+        col = np.zeros(n, dtype=np.int32)
+        _chk(self.L, self.L.topay_connect_collision(self.h, map_id, n, _ip(pn), _dp(car), _dp(qf), _dp(qt), _ip(col)))
+        return col.astype(bool), pn
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

@@ -19,6 +19,7 @@
 #include "topay_solve.h"
 #include "topay_feas.h"
 #include "topay_edt.h"
+#include "topay_front.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
 // One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
@@ -1253,6 +1254,19 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
     share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
     used += share[k];
   }
+  // The two classes of long candidates are not throughput-limited but latency-limited: a single candidate of theirs runs
+  // 0.5 .. 1.5 s, as long as the whole rest of the batch.  Give every one of them its own workgroup from the start (up to
+  // a cap) instead of a work-proportional share that would run them two or three deep.
+  for (int k = 3; k < topay_ctx::NBUCKET; k++) {
+    const int nk = (int)c->cls[k].size();
+    const int want = std::min(nk, 96);
+    if (want > share[k]) { used += want - share[k]; share[k] = want; }
+  }
+  for (int k = 0; used > slots && k < 3; k++) {   // ... taken from the common classes
+    const int give = std::min(used - slots, std::max(0, share[k] - 1));
+    share[k] -= give;
+    used -= give;
+  }
   for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
     const int kk = k % topay_ctx::NBUCKET;
     if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
@@ -1733,6 +1747,98 @@ topay_status topay_whole_body_collision(topay_ctx* c, int map_id, int n, const d
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(collide, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return TOPAY_OK;
+}
+
+// GraphSearch::getDensePath (graph_search.cpp:119-176) for n_paths raw 2-D paths at once.
+topay_status topay_dense_path(topay_ctx* c, int n_paths, const int* raw_len, const double* raw_xy, double step_size, const double* start_yaw,
+                              const double* end_yaw, double v_max, double w_max, int cap_per_path, int* out_len, double* out) {
+  if (!c || n_paths <= 0 || !raw_len || !raw_xy || !start_yaw || !end_yaw || !out_len || !out || cap_per_path <= 0 || !(step_size > 0.0))
+    return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<long long> off((size_t)n_paths + 1, 0);
+  for (int p = 0; p < n_paths; p++) {
+    if (raw_len[p] < 1) return TOPAY_ERR_INVALID_ARG;
+    off[p + 1] = off[p] + raw_len[p];
+  }
+  const size_t tot = (size_t)off[n_paths];
+  DevBuf d_raw, d_off, d_len, d_yaw, d_out, d_olen;
+  topay_status s;
+  if ((s = d_raw.ensure(tot * 16)) != TOPAY_OK || (s = d_off.ensure(((size_t)n_paths + 1) * 8)) != TOPAY_OK ||
+      (s = d_len.ensure((size_t)n_paths * 4)) != TOPAY_OK || (s = d_yaw.ensure((size_t)n_paths * 16)) != TOPAY_OK ||
+      (s = d_out.ensure((size_t)n_paths * cap_per_path * 32)) != TOPAY_OK || (s = d_olen.ensure((size_t)n_paths * 4)) != TOPAY_OK)
+    return s;
+  HIPCHK(hipMemcpyAsync(d_raw.p, raw_xy, tot * 16, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_off.p, off.data(), ((size_t)n_paths + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_len.p, raw_len, (size_t)n_paths * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_yaw.p, start_yaw, (size_t)n_paths * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_yaw.as<double>() + n_paths, end_yaw, (size_t)n_paths * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_dense_path, dim3((n_paths + 63) / 64), dim3(64), 0, c->stream, n_paths, (const double*)d_raw.as<double>(),
+                     (const long long*)d_off.as<long long>(), (const int*)d_len.as<int>(), step_size, (const double*)d_yaw.as<double>(),
+                     (const double*)(d_yaw.as<double>() + n_paths), v_max, w_max, cap_per_path, d_out.as<double>(), d_olen.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_len, d_olen.p, (size_t)n_paths * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out, d_out.p, (size_t)n_paths * cap_per_path * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  DevBuf* bufs[] = {&d_raw, &d_off, &d_len, &d_yaw, &d_out, &d_olen};
+  for (DevBuf* b : bufs) b->release();
+  return TOPAY_OK;
+}
+
+// MCRRTs::connectCollision (mcrrts.h:310-348): number of checks of every edge (lines 321-328; host arithmetic) ...
+topay_status topay_connect_check_num(int n_edges, const double* rs_distance, const double* q_from, const double* q_to, double check_res,
+                                     int* piece_num) {
+  if (n_edges < 0 || !rs_distance || !q_from || !q_to || !piece_num || !(check_res > 0.0)) return TOPAY_ERR_INVALID_ARG;
+  for (int e = 0; e < n_edges; e++) {
+    const int check_num_car = (int)std::ceil(rs_distance[e] / check_res);
+    double dmax = 0.0;
+    for (int q = 0; q < 7; q++) dmax = std::max(dmax, std::fabs(q_to[7 * e + q] - q_from[7 * e + q]));
+    const int check_num_theta = (int)std::ceil(dmax / check_res);
+    piece_num[e] = std::max(std::max(check_num_car, check_num_theta), 3);
+  }
+  return TOPAY_OK;
+}
+
+// ... and the checks themselves (lines 330-345), every interpolated state of every edge in one launch.
+topay_status topay_connect_collision(topay_ctx* c, int map_id, int n_edges, const int* piece_num, const double* car_poses, const double* q_from,
+                                     const double* q_to, int* collide) {
+  if (!c || n_edges < 0 || map_id < 0 || map_id >= TOPAY_MAX_MAPS || (n_edges > 0 && (!piece_num || !car_poses || !q_from || !q_to || !collide)))
+    return TOPAY_ERR_INVALID_ARG;
+  if (!c->have_map[map_id]) return TOPAY_ERR_NO_MAP;
+  if (n_edges == 0) return TOPAY_OK;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<int> edge_of, idx;
+  for (int e = 0; e < n_edges; e++) {
+    if (piece_num[e] <= 0) return TOPAY_ERR_INVALID_ARG;
+    for (int i = 0; i < piece_num[e]; i++) { edge_of.push_back(e); idx.push_back(i); }
+  }
+  const size_t nc = edge_of.size();
+  DevBuf d_i, d_d;
+  topay_status s;
+  if ((s = d_i.ensure((2 * nc + 2 * (size_t)n_edges) * 4)) != TOPAY_OK || (s = d_d.ensure((3 * nc + 14 * (size_t)n_edges) * 8)) != TOPAY_OK) return s;
+  int* d_edge = d_i.as<int>();
+  int* d_idx = d_edge + nc;
+  int* d_pn = d_idx + nc;
+  int* d_col = d_pn + n_edges;
+  double* d_car = d_d.as<double>();
+  double* d_qf = d_car + 3 * nc;
+  double* d_qt = d_qf + 7 * (size_t)n_edges;
+  HIPCHK(hipMemcpyAsync(d_edge, edge_of.data(), nc * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_idx, idx.data(), nc * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_pn, piece_num, (size_t)n_edges * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(d_col, 0, (size_t)n_edges * 4, c->stream));
+  HIPCHK(hipMemcpyAsync(d_car, car_poses, 3 * nc * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_qf, q_from, 7 * (size_t)n_edges * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_qt, q_to, 7 * (size_t)n_edges * 8, hipMemcpyHostToDevice, c->stream));
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  hipLaunchKernelGGL(k_connect, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, map_id, (long long)nc,
+                     (const int*)d_edge, (const int*)d_idx, (const int*)d_pn, (const double*)d_car, (const double*)d_qf, (const double*)d_qt, d_col);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(collide, d_col, (size_t)n_edges * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  d_i.release();
+  d_d.release();
   return TOPAY_OK;
 }
 
