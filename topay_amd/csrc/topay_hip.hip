@@ -1254,19 +1254,6 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
     share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
     used += share[k];
   }
-  // The two classes of long candidates are not throughput-limited but latency-limited: a single candidate of theirs runs
-  // 0.5 .. 1.5 s, as long as the whole rest of the batch.  Give every one of them its own workgroup from the start (up to
-  // a cap) instead of a work-proportional share that would run them two or three deep.
-  for (int k = 3; k < topay_ctx::NBUCKET; k++) {
-    const int nk = (int)c->cls[k].size();
-    const int want = std::min(nk, 96);
-    if (want > share[k]) { used += want - share[k]; share[k] = want; }
-  }
-  for (int k = 0; used > slots && k < 3; k++) {   // ... taken from the common classes
-    const int give = std::min(used - slots, std::max(0, share[k] - 1));
-    share[k] -= give;
-    used -= give;
-  }
   for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
     const int kk = k % topay_ctx::NBUCKET;
     if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
