@@ -38,7 +38,66 @@ def kernel_table(lib):
     return rows
 
 
+def disassemble(lib):
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        co = os.path.join(td, "gfx950.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={fat}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"])
+        return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", co], text=True)
+
+
+def spill_sites(lib, md):
+    """Where the scratch accesses sit: per function of the code object, the scratch_load / scratch_store instructions
+    by loop depth (number of enclosing backward branches -- depth 0 = straight-line prologue / epilogue code of the
+    function, executed once per call)."""
+    funcs, cur = {}, None
+    for line in disassemble(lib).splitlines():
+        m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
+        if m:
+            cur = m.group(2)
+            funcs[cur] = dict(start=int(m.group(1), 16), ins=[])
+            continue
+        m = re.match(r"^\s+(\S+)\s.*//\s*([0-9A-F]+):", line)
+        if m and cur:
+            tgt = None
+            if m.group(1).startswith(("s_cbranch", "s_branch")):
+                t = re.search(r"<\S+\+0x([0-9a-f]+)>\s*$", line)
+                t0 = re.search(r"<(\S+)>\s*$", line)
+                if t:
+                    tgt = funcs[cur]["start"] + int(t.group(1), 16)
+                elif t0 and "+" not in t0.group(1):
+                    tgt = funcs[cur]["start"]
+            funcs[cur]["ins"].append((int(m.group(2), 16), m.group(1), tgt))
+    hdr = ["function", "instructions", "scratch loads", "scratch stores",
+           "scratch instructions by innermost enclosing loop: loop extent in bytes of code -> count (`-` = outside any loop)"]
+    if md:
+        print("| " + " | ".join(hdr) + " |")
+        print("|" + "---|" * len(hdr))
+    for name, f in funcs.items():
+        loops = sorted({(t, a) for (a, op, t) in f["ins"] if t is not None and t <= a})
+        groups = {}
+        nl = ns = 0
+        for (a, op, t) in f["ins"]:
+            if not op.startswith("scratch_"):
+                continue
+            nl += op.startswith("scratch_load")
+            ns += op.startswith("scratch_store")
+            enc = [(hi - lo, lo, hi) for (lo, hi) in loops if lo <= a <= hi]
+            key = min(enc)[0] if enc else 0
+            groups[key] = groups.get(key, 0) + 1
+        if nl + ns == 0:
+            continue
+        by = ", ".join(f"{'-' if k == 0 else k} -> {v}" for k, v in sorted(groups.items(), key=lambda kv: (kv[0] == 0, -kv[0])))
+        vals = [f"`{name}`", len(f["ins"]), nl, ns, by]
+        print("| " + " | ".join(str(v) for v in vals) + " |" if md else vals)
+
+
 def main():
+    if "--spill-sites" in sys.argv:
+        a = [x for x in sys.argv[1:] if not x.startswith("--")]
+        return spill_sites(a[0] if a else os.path.join(ROOT, "topay_amd", "lib", "libtopay_hip.so"), "--md" in sys.argv)
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lib = args[0] if args else os.path.join(ROOT, "topay_amd", "lib", "libtopay_hip.so")
     rows = kernel_table(lib)

@@ -32,7 +32,7 @@ def main(src, dst, tag):
                        "accum_vgpr_count, sgpr_count from kernels where name like 'k_solve%' order by start")
     t0 = rows[0][2]
     out.append("")
-    out.append("## Solve-kernel dispatches (persistent: one per N-class, concurrent on three streams; grid = the class's share of the SIMD slots)")
+    out.append("## Solve-kernel dispatches (persistent: one per N-class, concurrent on one stream each; grid = the class's share of the SIMD slots)")
     out.append("")
     out.append("| kernel | queue | start ms | duration ms | workgroups | LDS B | scratch B/lane | arch VGPR | AGPR | SGPR |")
     out.append("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
@@ -75,12 +75,16 @@ def main(src, dst, tag):
         for r in rows2:
             out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {(r[2] - t0) / 1e6:.1f} | {(r[3] - t0) / 1e6:.1f} | {r[4] / 1e6:.1f} | {r[5] // 64} |")
         ends = sorted(r[3] for r in rows2)
-        # one step = three launches; the step's end = its last launch's end
-        by_step = [max(r[3] for r in rows2[i:i + 3]) for i in range(0, len(rows2) - len(rows2) % 3, 3)]
+        # one step = one launch per class, issued together; the step's end = its last launch's end
+        per = len({r[0] for r in rows2})
+        by_step = [max(r[3] for r in rows2[i:i + per]) for i in range(0, len(rows2) - len(rows2) % per, per)]
         if len(by_step) > 2:
             cad = [(b - a) / 1e6 for a, b in zip(by_step[1:-1], by_step[2:])]
             out.append("")
-            out.append(f"- time between the ends of consecutive timed steps: {', '.join(f'{c:.0f}' for c in cad)} ms")
+            out.append(f"- time between the ends of consecutive timed steps: {', '.join(f'{c:.0f}' for c in cad)} ms "
+                       f"(mean {sum(cad) / len(cad):.0f}; negative = a step whose long-candidate launch ended before the previous step's)")
+            sts = [min(r[2] for r in rows2[i:i + per]) for i in range(0, len(rows2) - len(rows2) % per, per)]
+            out.append(f"- time between the starts of consecutive steps: {', '.join(f'{(b - a) / 1e6:.0f}' for a, b in zip(sts[1:-1], sts[2:]))} ms")
         try:
             b = json.loads(open(os.path.join(src, "bench_kt2.json")).read().strip().splitlines()[-1])
             out.append(f"- bench.py under the profiler: value = {b['value']:.1f} {b['unit']}, ms_per_step = {b['ms_per_step']:.1f}, "
