@@ -313,8 +313,8 @@ def main():
     try:
         import glob
 
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if cands and S == 1024 and Ccand == 8 and not hires:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_hires.json" if hires else "r*_traffic.json")))
+        if cands and S == 1024 and Ccand == 8:
             tj = json.load(open(cands[-1]))
             traffic = float(tj["traffic_bytes"])
             traffic_src = os.path.relpath(cands[-1], ROOT)

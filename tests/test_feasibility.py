@@ -18,6 +18,21 @@ def _oracle_gate(m, path, x, alm):
     return o, o.check_feasible()
 
 
+@pytest.fixture(scope="module")
+def emu_partly_solved(cuboids_small):
+    """Three candidates taken part of the way by the kernel sources in the lane emulator.  The gate and the playback
+    are functions of the returned spline, whatever its state of convergence, and a full emulated solve takes most of a
+    minute per candidate: the inner iterations are capped (the one full solve is in the too-fast test below)."""
+    cs = cuboids_small
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 40
+    p.alm_max_outer = 2
+    emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    emu.optimizeTraj(cs["lens"][:3], cs["paths"][:cs["offs"][3]])
+    return emu
+
+
 def test_oracle_playback_is_consistent(cuboids_small):
     """MomaTraj::getState at t = 0 / T reproduces the start state / the Simpson-integrated end knot of getTraj, joints
     and yaw follow the polynomial, and the report's extremes bound the sampled values."""
@@ -37,16 +52,13 @@ def test_oracle_playback_is_consistent(cuboids_small):
     assert (np.abs(mid[3:]) <= np.abs(rep[4:11]) + 1e-12).all()
 
 
-def test_gate_kernel_matches_oracle_on_cpu(cuboids_small):
-    cs = cuboids_small
-    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
-    set_map(emu, cs["world"])
-    lens, paths = cs["lens"][:4], cs["paths"][:cs["offs"][4]]
-    emu.optimizeTraj(lens, paths)
+def test_gate_kernel_matches_oracle_on_cpu(cuboids_small, emu_partly_solved):
+    cs, emu = cuboids_small, emu_partly_solved
+    paths = cs["paths"]
     f, st, rep = emu.check_feasible(report=True)
     assert (emu.check_feasible() == f).all()
     alm = emu.alm_state()
-    for b in range(4):
+    for b in range(3):
         _, (fo, so, ro) = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
         assert fo == f[b] and so == st[b]
         # extremes: 1e-10 relative (libm vs deterministic sin/cos, scan vs running sum in car_seq)
@@ -99,13 +111,10 @@ def test_gate_on_gpu_matches_emulator_and_oracle():
         assert np.allclose(np.abs(ro), rg[b], rtol=1e-9, atol=1e-11)
 
 
-def test_playback_matches_oracle(cuboids_small):
+def test_playback_matches_oracle(cuboids_small, emu_partly_solved):
     """car_seq and getState of the kernel sources (CPU lane emulator) against the oracle's MomaTraj restatement."""
-    cs = cuboids_small
-    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
-    set_map(emu, cs["world"])
-    lens, paths = cs["lens"][:2], cs["paths"][:cs["offs"][2]]
-    emu.optimizeTraj(lens, paths)
+    cs, emu = cuboids_small, emu_partly_solved
+    paths = cs["paths"]
     alm = emu.alm_state()
     for b in range(2):
         o, _ = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])

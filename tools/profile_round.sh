@@ -1,12 +1,14 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): kernel trace + stats of the bench command, then separate PMC passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass), then the counter calibration.  Outputs under gpurun_out/prof_$1.
+# usage: tools/profile_round.sh [round tag] [hires]   -- with `hires`: the same three passes on BASELINE configs[4] (4 GB field) only
 R=${1:-r02}
+WL=$2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_$R
+OUT=$ROOT/gpurun_out/prof_$R${WL:+_$WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1"   # strictly serial steps: launches of different steps do not overlap, per-launch figures are well defined
+ARGS="--gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1${WL:+ --workload $WL}"   # strictly serial steps: launches of different steps do not overlap, per-launch figures are well defined
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $ROOT/bench.py $ARGS > $OUT/bench_kt.json 2> $OUT/kt.log
 # counter passes serialise the kernels of a step: with the queues shared between the classes the first launch (115
 # workgroups) would then solve the whole batch alone, out of L2 -- not the memory behaviour of the real, concurrent run.
@@ -15,6 +17,10 @@ export TOPAY_STEAL=0
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log
 unset TOPAY_STEAL
+if [ -n "$WL" ]; then
+  python3 $ROOT/bench.py $ARGS > $OUT/bench_plain.json 2>/dev/null
+  du -sh $OUT; exit 0
+fi
 [ -x $ROOT/tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/tools/pmc_calib $ROOT/tools/pmc_calib.hip 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- $ROOT/tools/pmc_calib > $OUT/calib.txt 2> $OUT/cal_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- $ROOT/tools/pmc_calib >> $OUT/calib.txt 2> $OUT/cal_write.log

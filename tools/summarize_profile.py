@@ -15,12 +15,12 @@ def q(db, sql):
     return cols, cur.fetchall()
 
 
-def main(src, dst, tag):
+def main(src, dst, tag, suffix=""):
     os.makedirs(dst, exist_ok=True)
     out = []
     kt = os.path.join(src, "kt", "kt_results.db")
     cols, rows = q(kt, "select name, total_calls, total_duration, average, percentage from top_kernels")
-    out.append(f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1")
+    out.append(f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-config1 --inflight 1" + (" --workload hires  (BASELINE configs[4]: one 50 x 50 x 1.6 m map at 0.02 m, 4 GB 3-D field)" if suffix else ""))
     out.append("")
     out.append("## Kernel statistics (durations in microseconds)")
     out.append("")
@@ -140,10 +140,10 @@ def main(src, dst, tag):
         out.append(f"- traffic = 2 x FETCH_SIZE + WRITE_SIZE = {(2 * f + w) / 1e9:.1f} GB per step "
                    f"(upper bound: the gather share of the reads needs no x2)")
         json.dump({"fetch_bytes_reported": f, "write_bytes": w, "traffic_bytes": 2 * f + w},
-                  open(os.path.join(dst, f"{tag}_traffic.json"), "w"))
-    open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
+                  open(os.path.join(dst, f"{tag}_traffic{suffix}.json"), "w"))
+    open(os.path.join(dst, f"{tag}_rocprof_summary{suffix}.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r01")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r01", sys.argv[4] if len(sys.argv) > 4 else "")
