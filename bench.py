@@ -80,8 +80,8 @@ def main():
                          "voxels (--hires-size metres square; 50 = the 4 GB 3-D ESDF) shared by all scenarios")
     ap.add_argument("--hires-size", type=float, default=50.0)
     ap.add_argument("--inflight", type=int, default=None,
-                    help="batches (contexts) in flight per GPU: step i+1 is issued while step i is still solving and its waves take the "
-                         "SIMDs step i's tail leaves idle; 1 = strictly serial steps (also measured and reported beside the line)")
+                    help="batches (contexts) in flight per GPU (default 3): step i+1 is issued while step i is still solving and its waves "
+                         "take the SIMDs step i's tail leaves idle; 1 = strictly serial steps (also measured and reported beside the line)")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +139,7 @@ def main():
         os.environ["TOPAY_CHAIN"] = "1"
     chain = os.environ.get("TOPAY_CHAIN") == "1"
     if args.inflight is None:
-        args.inflight = 3 if chain else 2
+        args.inflight = 3   # measured on one box (tools/ab_inflight.sh): 2 -> 7.9k, 3 -> 8.7-8.9k, 4 -> 7.9k (8.6k with 24 hardware queues) trajectories/s
     depth = max(1, args.inflight)
     opts = []
     map_ids_of = {}

@@ -20,7 +20,7 @@ def _oracle_gate(m, path, x, alm):
 
 @pytest.fixture(scope="module")
 def emu_partly_solved(cuboids_small):
-    """Three candidates taken part of the way by the kernel sources in the lane emulator.  The gate and the playback
+    """Four candidates taken part of the way by the kernel sources in the lane emulator.  The gate and the playback
     are functions of the returned spline, whatever its state of convergence, and a full emulated solve takes most of a
     minute per candidate: the inner iterations are capped (the one full solve is in the too-fast test below)."""
     cs = cuboids_small
@@ -29,8 +29,12 @@ def emu_partly_solved(cuboids_small):
     p.alm_max_outer = 2
     emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
     set_map(emu, cs["world"])
-    emu.optimizeTraj(cs["lens"][:3], cs["paths"][:cs["offs"][3]])
-    return emu
+    ok = emu.optimizeTraj(cs["lens"][:4], cs["paths"][:cs["offs"][4]])
+    # a candidate may end in one of the reference's L-BFGS error returns (the oracle does too, for about 1 % of the
+    # benchmark candidates): it has no trajectory to gate
+    solved = [int(b) for b in np.nonzero(ok)[0]]
+    assert len(solved) >= 2
+    return emu, solved
 
 
 def test_oracle_playback_is_consistent(cuboids_small):
@@ -53,12 +57,12 @@ def test_oracle_playback_is_consistent(cuboids_small):
 
 
 def test_gate_kernel_matches_oracle_on_cpu(cuboids_small, emu_partly_solved):
-    cs, emu = cuboids_small, emu_partly_solved
+    cs, (emu, solved) = cuboids_small, emu_partly_solved
     paths = cs["paths"]
     f, st, rep = emu.check_feasible(report=True)
     assert (emu.check_feasible() == f).all()
     alm = emu.alm_state()
-    for b in range(3):
+    for b in solved:
         _, (fo, so, ro) = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
         assert fo == f[b] and so == st[b]
         # extremes: 1e-10 relative (libm vs deterministic sin/cos, scan vs running sum in car_seq)
@@ -113,10 +117,10 @@ def test_gate_on_gpu_matches_emulator_and_oracle():
 
 def test_playback_matches_oracle(cuboids_small, emu_partly_solved):
     """car_seq and getState of the kernel sources (CPU lane emulator) against the oracle's MomaTraj restatement."""
-    cs, emu = cuboids_small, emu_partly_solved
+    cs, (emu, solved) = cuboids_small, emu_partly_solved
     paths = cs["paths"]
     alm = emu.alm_state()
-    for b in range(2):
+    for b in solved[:2]:
         o, _ = _oracle_gate(cs["map"], paths[cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
         T = emu.total_durations()[b]
         times = np.concatenate([[0.0, T, T + 1.0, -0.5], np.linspace(0, T, 37)])

@@ -66,7 +66,7 @@ _libs = {}
 
 def load(path=None):
     """Load the C-ABI library.  Default: the hipcc-built product library; raises if it is missing."""
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.abspath(path or os.environ.get("TOPAY_LIB") or DEFAULT_LIB)   # TOPAY_LIB: diagnostic A/B of two builds
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):

@@ -1258,6 +1258,15 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
     const int kk = k % topay_ctx::NBUCKET;
     if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
   }
+  // The two classes of long candidates share one pool of workgroups (a class-6 workgroup also serves class 4, not the
+  // other way round): the longest class first gets one workgroup per candidate as far as the pool goes, so that no
+  // 43..64-piece candidate -- the longest single solves of a batch -- queues behind another one.
+  static const bool pool_big = [] { const char* e = getenv("TOPAY_BIG_POOL"); return e && e[0] == '1'; }();
+  if (pool_big && topay_ctx::NBUCKET == 5 && share[4] > 0) {
+    const int pool = share[3] + share[4], n3 = (int)c->cls[3].size(), n4 = (int)c->cls[4].size();
+    share[4] = std::min(n4, pool - (n3 > 0 ? 1 : 0));
+    share[3] = std::min(n3, pool - share[4]);
+  }
 }
 
 // Kernel of launch class k (rows per lane 1 / 2 / 3 / 4 / 6).  The class index selects the template -- also when the

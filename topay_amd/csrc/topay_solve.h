@@ -14,6 +14,9 @@
 #ifndef TOPAY_PF_ELEMS
 #define TOPAY_PF_ELEMS 24
 #endif
+#ifndef TOPAY_PF_MAX
+#define TOPAY_PF_MAX 12
+#endif
 
 namespace topay {
 
@@ -33,23 +36,39 @@ struct SolveIO {
   int trace_cap;
 };
 
-// Vector operations on the n-element L-BFGS vectors (element e = lane + 64 t, t < EPL, n <= 64 EPL).  Every load of
-// an operation is issued before its arithmetic (clamped index + mask instead of a trip-count loop, whose iterations
-// the compiler serialises): a single wave has nothing else to hide the HBM / L2 latency behind.
+// Vector operations on the n-element L-BFGS vectors.  A lane owns EPL / 2 pairs of adjacent elements: register t holds
+// element 128 (t / 2) + 2 lane + (t % 2), n <= 64 EPL, n even (10 N - 8), every vector and history row starts on a
+// 16-byte boundary (n_max is even) -- so a pair moves with one 16-byte load or store: half the memory instructions per
+// byte, which is what bounds a single wave (the counter of outstanding loads has 63 steps, whatever their width).
+// Every load of an operation is issued before its arithmetic (clamped index + mask instead of a trip-count loop, whose
+// iterations the compiler serialises): a single wave has nothing else to hide the HBM / L2 latency behind.
+typedef double dpair __attribute__((vector_size(16)));   // plain vector type: loads through address-space pointers need no constructor
+typedef const TOPAY_GLB dpair* glb_cpp;
+typedef TOPAY_GLB dpair* glb_pp;
+__device__ __forceinline__ bool vec_in(int lane, int t, int n) { return 128 * (t >> 1) + 2 * lane < n; }
 template <int EPL>
 __device__ __forceinline__ void vec_load(glb_cdp a, int n, int lane, double (&v)[EPL]) {
+  static_assert(EPL % 2 == 0, "pairs");
+  const glb_cpp ap = (glb_cpp)a;
+  const int last = (n >> 1) - 1;
 #pragma unroll
-  for (int t = 0; t < EPL; t++) {
-    const int e = lane + 64 * t;
-    v[t] = a[e < n ? e : n - 1];
+  for (int p = 0; p < EPL / 2; p++) {
+    const int i = 64 * p + lane;
+    const dpair q = ap[i <= last ? i : last];
+    v[2 * p] = q[0];
+    v[2 * p + 1] = q[1];
   }
 }
 template <int EPL>
 __device__ __forceinline__ void vec_store(glb_dp a, int n, int lane, const double (&v)[EPL]) {
+  const glb_pp ap = (glb_pp)a;
 #pragma unroll
-  for (int t = 0; t < EPL; t++) {
-    const int e = lane + 64 * t;
-    if (e < n) a[e] = v[t];
+  for (int p = 0; p < EPL / 2; p++) {
+    const int i = 64 * p + lane;
+    dpair q;
+    q[0] = v[2 * p];
+    q[1] = v[2 * p + 1];
+    if (2 * i < n) ap[i] = q;
   }
 }
 // sum over the lane's elements in ascending t, then the fixed wave tree (same order as a plain strided loop)
@@ -60,7 +79,7 @@ __device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane)
   vec_load<EPL>(b, n, lane, bv);
   double s = 0.0;
 #pragma unroll
-  for (int t = 0; t < EPL; t++) s += (lane + 64 * t < n) ? av[t] * bv[t] : 0.0;
+  for (int t = 0; t < EPL; t++) s += vec_in(lane, t, n) ? av[t] * bv[t] : 0.0;
   return wave_sum(s);
 }
 
@@ -177,7 +196,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         vec_load<EPL>(S.x, n, lane, xv);
 #pragma unroll
         for (int t = 0; t < EPL; t++) {
-          const bool in = lane + 64 * t < n;
+          const bool in = vec_in(lane, t, n);
           dv[t] = -gv[t];
           gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
           xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
@@ -265,7 +284,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             vec_load<EPL>(S.x, n, lane, xv);
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-              const bool in = lane + 64 * t < n;
+              const bool in = vec_in(lane, t, n);
               gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
               xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
             }
@@ -302,7 +321,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             vec_load<EPL>(S.gp, n, lane, qv);
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-              const bool in = lane + 64 * t < n;
+              const bool in = vec_in(lane, t, n);
               const double se = xv[t] - pv[t], ye = gv[t] - qv[t], gpe = qv[t];
               sv[t] = se;
               yv[t] = ye;
@@ -323,21 +342,21 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             bound = mem < bound ? mem : bound;
             end = (end + 1) % mem;
             if (stage == 2) st_sumb += bound;
-            // two-loop recursion (lbfgs.hpp:691-710) with the direction held in registers (element e = lane + 64 t).
+            // two-loop recursion (lbfgs.hpp:691-710) with the direction held in registers (pairs of adjacent elements per lane, see vec_load).
             // History pairs stream from HBM through a PF-deep ring of register slots so that PF loads are always in flight
             // while the dependent dot-product / axpy chain runs.
             // Only loads may be in flight inside the loops (one store would make the memory counter unordered and
             // every wait a full drain), and every load is issued unconditionally so that the number outstanding is
             // static: the alpha values live in LDS (256 doubles) and the prefetch keeps running past the end (it re-reads
             // valid, unused rows).
-            constexpr int PF = TOPAY_PF_ELEMS / EPL;  // pairs in flight
+            constexpr int PF = TOPAY_PF_ELEMS / EPL < TOPAY_PF_MAX ? TOPAY_PF_ELEMS / EPL : TOPAY_PF_MAX;  // pairs in flight
             SUBSTAMP_BEGIN(C);
             double dr[EPL];
             {
               double gv[EPL];
               vec_load<EPL>(S.g, n, lane, gv);
 #pragma unroll
-              for (int t = 0; t < EPL; t++) dr[t] = (lane + 64 * t < n) ? -gv[t] : 0.0;
+              for (int t = 0; t < EPL; t++) dr[t] = vec_in(lane, t, n) ? -gv[t] : 0.0;
             }
             double sb[PF][EPL], yb[PF][EPL], rb[PF];
             lds_dp alpha = pf + 8;  // [mem <= 256]: every lane writes / reads the same entry (LDS broadcast)
@@ -346,15 +365,18 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             const int endu = __builtin_amdgcn_readfirstlane(end), boundu = __builtin_amdgcn_readfirstlane(bound);
             const int memu = __builtin_amdgcn_readfirstlane(mem), nstr = __builtin_amdgcn_readfirstlane(S.nstride);
             auto load_pair = [&](int slot, int jj) {
-              glb_cdp sj = S.hist_s + (size_t)jj * nstr;
-              glb_cdp yj = S.hist_y + (size_t)jj * nstr;
+              const glb_cpp sj = (glb_cpp)(S.hist_s + (size_t)jj * nstr);
+              const glb_cpp yj = (glb_cpp)(S.hist_y + (size_t)jj * nstr);
+              const int last = (n >> 1) - 1;
 #pragma unroll
-              for (int t = 0; t < EPL; t++) {
-                const int e = lane + 64 * t;
-                const int ec = e < n ? e : n - 1;
-                const double sv = sj[ec], yv = yj[ec];
-                sb[slot][t] = e < n ? sv : 0.0;
-                yb[slot][t] = e < n ? yv : 0.0;
+              for (int p = 0; p < EPL / 2; p++) {
+                const int i = 64 * p + lane;
+                const bool in = i <= last;
+                const dpair sv = sj[in ? i : last], yv = yj[in ? i : last];
+                sb[slot][2 * p] = in ? sv[0] : 0.0;
+                sb[slot][2 * p + 1] = in ? sv[1] : 0.0;
+                yb[slot][2 * p] = in ? yv[0] : 0.0;
+                yb[slot][2 * p + 1] = in ? yv[1] : 0.0;
               }
               rb[slot] = S.hist_ys[jj];
             };
@@ -412,11 +434,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                 jl = jl + 1 == memu ? 0 : jl + 1;
               }
             }
-#pragma unroll
-            for (int t = 0; t < EPL; t++) {
-              const int e = lane + 64 * t;
-              if (e < n) S.d[e] = dr[t];
-            }
+            vec_store<EPL>(S.d, n, lane, dr);
             SUBSTAMP_END(C, 10);  // two-loop recursion
           }
           step = 1.0;
