@@ -252,9 +252,21 @@ def test_config2_tables_64_candidates():
     assert (st[:, :3] == r["stats"][:, :3]).mean() > 0.95
     assert abs(ok.mean() - r["success"].mean()) <= 0.1
     both = ok & (r["success"] == 1)
-    # cost distribution of the converged candidates: quartiles, not only the median
-    for q in (25, 50, 75):
-        assert abs(np.percentile(cost[both], q) / np.percentile(r["cost"][both], q) - 1.0) < 0.05, q
+    # Cost distribution of the converged candidates.  It is multi-modal (the 64 candidates of one scenario end in a few
+    # local minima: around 358, 590, 700, 760 here) and a candidate near a watershed may end in another minimum than
+    # the oracle's run of it, so single quantiles next to a gap between modes are ill-conditioned.  Asserted instead:
+    # (a) most candidates end in the oracle's minimum of the same candidate (costs within 5 %), (b) the two empirical
+    # distributions agree at every decile within 5 % in value and 0.15 in rank (a Kolmogorov-Smirnov band; the 5 %
+    # critical distance for two samples of 60 is 0.25).
+    dev, ref = cost[both], r["cost"][both]
+    same = np.abs(dev / ref - 1.0) < 0.05
+    print(f"config2: {both.sum()} converged in both, {same.mean():.2f} in the same minimum; deciles dev/ref: "
+          f"{[round(float(np.percentile(dev, q) / np.percentile(ref, q)), 3) for q in range(10, 100, 10)]}")
+    assert same.mean() > 0.7
+    assert abs(np.median(dev) / np.median(ref) - 1.0) < 0.05
+    for q in range(10, 100, 10):
+        v = np.percentile(ref, q)
+        assert np.mean(dev <= 1.05 * v) >= q / 100 - 0.15 and np.mean(dev < 0.95 * v) <= q / 100 + 0.15, q
     # Converged values cannot be compared one by one (chaotic iteration), and the reference's stop
     # test (three past costs within 1e-4) also fires on plateaus: restarted at its own result, the reference algorithm
     # itself moves on by more than 1e-3 in a quarter of the cases (tools/restart_experiment.py).  What can be asserted
