@@ -122,3 +122,45 @@ def test_reference_side_adapter_compiles_against_the_header():
                         "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "examples"),
                         os.path.join(ROOT, "examples", "adapter_syntax_check.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_parameter_file_loader_follows_the_reference_keys():
+    """params_from_yaml == MomaTrajOpt::init (moma_traj_opt.h:845-941): keys of the reference's optimizer.yaml land in
+    the fields the kernels read; the keys the path has no use for are reported, unknown keys too."""
+    text = """
+planner_node:
+  moma_traj_opt:
+    int_K: 12
+    sample_interval: 1.25
+    mean_time_lowb: 0.4
+    energy_weights: [0.5, 1, 1, 1, 1, 1, 1, 1, 2]
+    first_stage:
+      time_weight: 21.0
+      lbgfs_normal_past: 4
+      lbfgs: {mem_size: 128, delta: 2.0e-2}
+    second_stage:
+      collision_weight: 123456.0
+      mean_time_weight: 7.0
+      lbfgs: {past: 5, min_step: 1.0e-30, max_iterations: 77}
+      alm_param:
+        init_rho: [2.0e4, 3.0e4, 1, 1, 1, 1, 1, 1, 1]
+        tolerance: [0.02]
+      alm_data: {max_iter: 100}
+    no_such_key: 1
+"""
+    d = api.default_params()
+    p, ignored = api.params_from_yaml(text)
+    assert p.sample_interval == 1.25 and p.energy_weights[0] == 0.5 and p.energy_weights[8] == 2.0
+    assert p.s1_time_weight == 21.0 and p.s1_normal_past == 4 and p.s1_lbfgs.past == 4
+    assert p.s1_lbfgs.mem_size == 128 and p.s1_lbfgs.delta == 2.0e-2 and p.s1_lbfgs.max_iterations == d.s1_lbfgs.max_iterations
+    assert p.s2_collision_weight == 123456.0 and p.s2_mean_time_weight == 7.0
+    assert p.s2_lbfgs.past == 5 and p.s2_lbfgs.min_step == 1.0e-30 and p.s2_lbfgs.max_iterations == 77
+    assert list(p.alm_init_rho) == [2.0e4, 3.0e4] and p.alm_tolerance == 0.02 and list(p.alm_gamma) == list(d.alm_gamma)
+    assert p.s2_mani_pos_weight == d.s2_mani_pos_weight and p.max_v == d.max_v       # untouched keys keep the defaults
+    assert sorted(ignored) == ["mean_time_lowb", "no_such_key", "second_stage/alm_data/max_iter"]
+    ref = "/root/reference/src/planner/params/optimizer.yaml"
+    if os.path.exists(ref):      # build container only: the reference's own file gives exactly the built-in defaults
+        q, ign = api.params_from_yaml(ref)
+        assert bytes(q) == bytes(d)
+        assert sorted(ign) == ["first_stage/mean_time_weight", "mean_time_lowb", "mean_time_uppb", "second_stage/alm_data/epsilon_con",
+                               "second_stage/alm_data/max_iter"]

@@ -24,7 +24,7 @@ fi
 [ -x $ROOT/tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/tools/pmc_calib $ROOT/tools/pmc_calib.hip 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- $ROOT/tools/pmc_calib > $OUT/calib.txt 2> $OUT/cal_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- $ROOT/tools/pmc_calib >> $OUT/calib.txt 2> $OUT/cal_write.log
-# the default (pipelined, two batches in flight) command under the kernel trace, then plain
+# the default (pipelined, three batches in flight) command under the kernel trace, then plain
 rocprofv3 --kernel-trace --stats -d $OUT/kt2 -o kt -- python3 $ROOT/bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial > $OUT/bench_kt2.json 2> $OUT/kt2.log
 python3 $ROOT/bench.py $ARGS > $OUT/bench_plain.json 2>/dev/null
 python3 $ROOT/bench.py > $OUT/bench_default.json 2>/dev/null

@@ -66,7 +66,7 @@ def main(src, dst, tag, suffix=""):
         cols, rows2 = q(kt2, "select name, queue_id, start, end, duration, grid_x from kernels where name like 'k_solve%' order by start")
         t0 = rows2[0][2]
         out.append("")
-        out.append("## Default command (two batches in flight): rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial")
+        out.append("## Default command (three batches in flight): rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial")
         out.append("")
         out.append("Launches of consecutive steps overlap: a batch's workgroups take the SIMDs the previous batch's exiting workgroups free.")
         out.append("")

@@ -127,6 +127,90 @@ def default_params(lib=None):
     return p
 
 
+def params_from_yaml(source, base=None, lib=None):
+    """== MomaTrajOpt::init (moma_traj_opt.h:845-941): the optimiser parameters from the reference's parameter file
+    (src/planner/params/optimizer.yaml: `planner_node: moma_traj_opt: ...`, the keys init() reads from the parameter
+    server).  `source` is a path, a YAML text or an already parsed mapping; keys that are absent keep the value of
+    `base` (default: topay_default_params).  Returns (Params, ignored): `ignored` lists the keys the reference reads
+    but this path has no use for -- mean_time_lowb / mean_time_uppb (the reference's penalty uses the literals 0.5 and
+    2.0, moma_traj_opt.cpp:1752-1769), first_stage/mean_time_weight (stage 1 has no mean-time term), alm_data/* (read
+    into a struct optimizeTraj never consults) -- and any key init() does not know."""
+    import yaml
+
+    if isinstance(source, dict):
+        doc = source
+    else:
+        text = open(source).read() if os.path.exists(str(source)) else str(source)
+        doc = yaml.safe_load(text) or {}
+    for k in ("planner_node", "moma_traj_opt"):
+        if isinstance(doc, dict) and k in doc:
+            doc = doc[k]
+    p = Params()
+    if base is not None:
+        C.memmove(C.byref(p), C.byref(base), C.sizeof(Params))
+    else:
+        _chk(lib or load(), (lib or load()).topay_default_params(C.byref(p)))
+    ignored = []
+
+    def vec(dst, src, n):
+        for i in range(min(n, len(src))):
+            dst[i] = float(src[i])
+
+    def lbfgs(dst, m, prefix):
+        for k, v in m.items():
+            if k in ("mem_size", "past", "max_iterations"):
+                setattr(dst, k, int(v))
+            elif k in ("g_epsilon", "min_step", "delta"):
+                setattr(dst, k, float(v))
+            else:
+                ignored.append(prefix + k)
+
+    for k, v in (doc or {}).items():
+        if k in ("int_K", "min_piece_num"):
+            setattr(p, k, int(v))
+        elif k in ("relu_mu", "sample_interval"):
+            setattr(p, k, float(v))
+        elif k == "energy_weights":
+            vec(p.energy_weights, v, 9)
+        elif k == "first_stage":
+            for kk, vv in v.items():
+                if kk in ("time_weight", "moment_weight", "acc_weight", "domega_weight", "path_pos_weight"):
+                    setattr(p, "s1_" + kk, float(vv))
+                elif kk == "lbgfs_normal_past":          # (sic) also becomes the stage-1 `past`, moma_traj_opt.h:873
+                    p.s1_normal_past = int(vv)
+                    p.s1_lbfgs.past = int(vv)
+                elif kk == "lbgfs_shot_path_past":
+                    p.s1_shot_path_past = int(vv)
+                elif kk == "shot_path_horizon":
+                    p.s1_shot_path_horizon = float(vv)
+                elif kk == "lbfgs":
+                    lbfgs(p.s1_lbfgs, {a: b for a, b in vv.items() if a != "past"}, "first_stage/lbfgs/")
+                    if "past" in vv:
+                        ignored.append("first_stage/lbfgs/past")
+                else:
+                    ignored.append("first_stage/" + kk)
+        elif k == "second_stage":
+            for kk, vv in v.items():
+                if kk in ("time_weight", "moment_weight", "acc_weight", "domega_weight", "collision_weight", "mani_colli_weight",
+                          "self_colli_weight", "mani_pos_weight", "mani_vel_weight", "mani_acc_weight", "mean_time_weight"):
+                    setattr(p, "s2_" + kk, float(vv))
+                elif kk == "lbfgs":
+                    lbfgs(p.s2_lbfgs, vv, "second_stage/lbfgs/")
+                elif kk == "alm_param":
+                    for a, b in vv.items():       # the reference sizes these vectors 9 and uses entries 0 and 1 (end-point x, y)
+                        if a in ("init_lambda", "init_rho", "rho_max", "gamma"):
+                            vec(getattr(p, "alm_" + a), b, 2)
+                        elif a == "tolerance":
+                            p.alm_tolerance = float(b[0])
+                        else:
+                            ignored.append("second_stage/alm_param/" + a)
+                else:
+                    ignored.extend(f"second_stage/{kk}/{a}" for a in vv) if isinstance(vv, dict) else ignored.append("second_stage/" + kk)
+        else:
+            ignored.append(k)
+    return p, ignored
+
+
 def _chk(L, status):
     if status != 0:
         raise TopayError(f"topay status {status}: {L.topay_last_error().decode()}")
