@@ -137,6 +137,12 @@ topay_status topay_default_params(topay_params_t* p);
 /* Create a context on HIP device `device` (use LOCAL_RANK for one process per GPU). */
 topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out);
 void topay_destroy(topay_ctx* ctx);
+
+/* == assigning MomaTrajOpt::opt_param (a public member the planner may change between calls, moma_traj_opt.h:616):
+ * replace the context's parameters.  Weights, L-BFGS and ALM settings take effect with the next solve / evaluation of
+ * the resident batch; a change of sample_interval, min_piece_num, the velocity / acceleration limits or the history
+ * depth invalidates the resident batch (call topay_set_init_traj again).  Waits for a solve in flight. */
+topay_status topay_set_params(topay_ctx* ctx, const topay_params_t* params);
 const char* topay_last_error(void);
 
 /* Upload a map; the context keeps a device copy.  Up to TOPAY_MAX_MAPS maps may be resident (the

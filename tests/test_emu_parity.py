@@ -67,6 +67,15 @@ def test_eval_rare_paths_match_oracle(emu, cuboids_small):
         fe, ge, _ = emu.eval(2, b, x, [0, 0], [1e4, 1e4])
         assert abs(f - fe) <= 1e-12 * abs(f)
         assert np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+        if b < 2:
+            # the per-term breakdown (DebugManager, moma_traj_opt.h:566-611) through topay_set_params + topay_eval
+            d = emu.cost_terms(b, x, [0.3, -0.2], [1e4, 2e4])
+            o.set_alm([0.3, -0.2], [1e4, 2e4])
+            f2, _ = o.eval(2, x)
+            t2 = o.debug_terms()
+            assert all(abs(d[k] - t2[k]) <= 1e-11 * max(abs(t2[k]), 1e-6 * abs(f2)) for k in t2), (d, t2)
+            assert abs(sum(d.values()) - f2) <= 1e-11 * abs(f2)
+            assert emu.eval(2, b, x, [0, 0], [1e4, 1e4])[0] == fe        # the context's own parameters are back
     assert t["self_colli"] >= 0
 
 

@@ -85,6 +85,27 @@ def test_eval_matches_oracle_and_emulator(gpu, emu, cuboids_small, stage):
             assert fg == fe and (gg == ge).all() and (eg == ee).all()  # bit-identical to the CPU execution
 
 
+def test_cost_terms_match_the_oracle_breakdown(gpu, cuboids_small):
+    """Per-term cost breakdown (DebugManager, moma_traj_opt.h:566-611) on the device through topay_set_params +
+    topay_eval against the oracle's accumulators, at a point where the rare terms are active."""
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    for b in (0, 3):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        N = o.N
+        x = o.get_x().copy()
+        x[:N] -= 1.6
+        x[N - 1] += 2.5
+        x[3 * N - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], N - 1)
+        o.set_alm([0.3, -0.2], [1e4, 2e4])
+        f, _ = o.eval(2, x)
+        t = o.debug_terms()
+        d = gpu.cost_terms(b, x, [0.3, -0.2], [1e4, 2e4])
+        assert t["mani_vel"] > 0 and t["mean_time"] > 0
+        assert all(abs(d[k] - t[k]) <= 1e-11 * max(abs(t[k]), 1e-6 * abs(f)) for k in t), (d, t)
+        assert abs(sum(d.values()) - f) <= 1e-11 * abs(f)
+
+
 def test_golden_fixture_evaluations(cuboids_small):
     import os
 

@@ -78,6 +78,7 @@ def load(path=None):
     L.topay_default_params.argtypes = [C.POINTER(Params)]
     L.topay_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
     L.topay_destroy.argtypes = [C.c_void_p]
+    L.topay_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.topay_set_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), c_dp, c_dp]
     L.topay_set_init_traj.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
     L.topay_reset.argtypes = [C.c_void_p]
@@ -517,6 +518,49 @@ class MomaTrajOptBatch:
         rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
         _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
         return f.value, g, e
+
+    def set_params(self, params=None):
+        """Push `opt_param` (or `params`) to the context: the reference's `opt_param` is a public member the planner may
+        change between calls (moma_traj_opt.h:616)."""
+        if params is not None:
+            self.opt_param = params
+        _chk(self.L, self.L.topay_set_params(self.h, C.byref(self.opt_param)))
+
+    COST_TERMS = ("jerk", "time", "chassis_colli", "moment", "acc", "domega", "mani_colli", "self_colli", "mani_pos",
+                  "mani_vel", "mani_acc", "mean_time", "endp")
+
+    def cost_terms(self, i, x, alm_lambda, alm_rho):
+        """Per-term breakdown of the stage-2 cost at x -- what the reference's DebugManager publishes under
+        /debug_cost/<name> (moma_traj_opt.h:566-611, names as in 930-941).  Every term carries its own weight, so term k
+        is the cost evaluated with every other weight at zero (the ALM term switched off by lambda = 0, rho = 1e-300):
+        13 evaluations through topay_eval with topay_set_params in between; a debugging aid, not a hot path."""
+        own = {"jerk": "energy_weights", "time": "s2_time_weight", "chassis_colli": "s2_collision_weight",
+               "moment": "s2_moment_weight", "acc": "s2_acc_weight", "domega": "s2_domega_weight",
+               "mani_colli": "s2_mani_colli_weight", "self_colli": "s2_self_colli_weight", "mani_pos": "s2_mani_pos_weight",
+               "mani_vel": "s2_mani_vel_weight", "mani_acc": "s2_mani_acc_weight", "mean_time": "s2_mean_time_weight"}
+        keep = Params()
+        C.memmove(C.byref(keep), C.byref(self.opt_param), C.sizeof(Params))
+        out = {}
+        try:
+            for name in self.COST_TERMS:
+                q = Params()
+                C.memmove(C.byref(q), C.byref(keep), C.sizeof(Params))
+                for term, field in own.items():
+                    if term == name:
+                        continue
+                    if field == "energy_weights":
+                        for k in range(9):
+                            q.energy_weights[k] = 0.0
+                    else:
+                        setattr(q, field, 0.0)
+                _chk(self.L, self.L.topay_set_params(self.h, C.byref(q)))
+                if name == "endp":
+                    out[name] = self.eval(2, i, x, alm_lambda, alm_rho)[0]
+                else:
+                    out[name] = self.eval(2, i, x, [0.0, 0.0], [1e-300, 1e-300])[0]
+        finally:
+            _chk(self.L, self.L.topay_set_params(self.h, C.byref(keep)))
+        return out
 
     def eval_batch(self, stage, repeats=1):
         f = np.zeros(self.batch)

@@ -691,8 +691,7 @@ topay_status topay_default_params(topay_params_t* p) {
   return TOPAY_OK;
 }
 
-topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out) {
-  if (!params || !out) return TOPAY_ERR_INVALID_ARG;
+static topay_status validate_params(const topay_params_t* params) {
   if (params->int_K != TOPAY_K) { set_err("int_K must be 12 in this build"); return TOPAY_ERR_UNSUPPORTED; }
   if (!sphere_layout_ok(*params)) { set_err("unsupported collision sphere layout"); return TOPAY_ERR_UNSUPPORTED; }
   if (params->s1_lbfgs.mem_size <= 0 || params->s2_lbfgs.mem_size <= 0 || params->s1_lbfgs.mem_size > 256 ||
@@ -701,6 +700,28 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     set_err("lbfgs mem_size must be in 1..256 (the reference uses 256) and past <= 8");
     return TOPAY_ERR_INVALID_ARG;
   }
+  return TOPAY_OK;
+}
+
+topay_status topay_set_params(topay_ctx* c, const topay_params_t* params) {
+  if (!c || !params) return TOPAY_ERR_INVALID_ARG;
+  topay_status vs = validate_params(params);
+  if (vs != TOPAY_OK) return vs;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  // what the resident batch was laid out with: number of pieces (init step) and history depth (workspace)
+  const bool relayout = params->sample_interval != c->hp.sample_interval || params->min_piece_num != c->hp.min_piece_num ||
+                        std::max(params->s1_lbfgs.mem_size, params->s2_lbfgs.mem_size) != std::max(c->hp.s1_lbfgs.mem_size, c->hp.s2_lbfgs.mem_size) ||
+                        params->max_v != c->hp.max_v || params->max_a != c->hp.max_a || params->max_w != c->hp.max_w || params->max_dw != c->hp.max_dw;
+  c->hp = *params;
+  make_dev_params(*params, c->dp);
+  if (relayout) { c->have_traj = false; c->solved = false; }
+  return TOPAY_OK;
+}
+
+topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out) {
+  if (!params || !out) return TOPAY_ERR_INVALID_ARG;
+  { topay_status vs = validate_params(params); if (vs != TOPAY_OK) return vs; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_err("no HIP device available: the MI355X HIP path is required (there is no CPU fallback)");
