@@ -280,6 +280,27 @@ topay_status topay_connect_collision(topay_ctx* ctx, int map_id, int n_edges, co
 topay_status topay_playback(topay_ctx* ctx, int i, int n_times, const double* times, double* states, int seq_cap,
                             double* seq, int* n_seq);
 
+/* Mesh kinematics of MomaParam that only getMeshPose uses (moma_param.h:60-67, 77-90, 114-115). */
+typedef struct topay_mesh_params_t {
+  double link_length[7];
+  double joint_pos_limit_min[7];
+  double joint_offset[21];   /* 7 x 3 row-major: roll, pitch, yaw of the fixed rotation before joint i */
+  double joint_dof_axis[21]; /* 7 x 3 row-major: the joint angle multiplies this (roll, pitch, yaw) triple */
+} topay_mesh_params_t;
+topay_status topay_default_mesh_params(topay_mesh_params_t* p);
+
+/* == MomaParam::getMeshPose (moma_param.h:724-790) for n states (x, y, theta, q1..q7): parts[n][11][7], rows = chassis,
+ * stump, link 1..7, end effector (a copy of link 7), end-effector collision point (position only, orientation zero);
+ * columns = x, y, z, qw, qx, qy, qz as in MeshPart.msg. */
+topay_status topay_mesh_poses(topay_ctx* ctx, const topay_mesh_params_t* mesh, int n, const double* states, double* parts);
+
+/* == Planner::toMeshMsg (planner.cpp:2003-2056) of candidate i, the MeshTraj message the planner publishes for the winner
+ * (planner.cpp:1014-1016): the trajectory sampled through MomaTraj::getState every T / res (res = 1000 in the
+ * reference; t accumulated and compared `t < T` as there, so *n_states is res or res + 1), per sample the 11 mesh
+ * poses, the yaw and the accumulated chassis arc length.  cap_states >= res + 1. */
+topay_status topay_mesh_traj(topay_ctx* ctx, int i, const topay_mesh_params_t* mesh, int res, int cap_states, double* parts,
+                             double* yaws, double* arc_lengths, int* n_states);
+
 /* Total duration of every candidate's returned trajectory (MomaTraj::getTotalDuration): the quantity the planner ranks
  * the successful candidates of a scenario by (planner.cpp:999-1010). */
 topay_status topay_get_total_durations(topay_ctx* ctx, double* total /* batch */);

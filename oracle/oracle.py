@@ -197,6 +197,20 @@ class Oracle:
         n = self.L.orc_car_seq(self.h, _dp(seq), 4096)
         return seq[:n].copy()
 
+    def mesh_pose(self, state):
+        """MomaParam::getMeshPose (moma_param.h:724-790): 11 x (x, y, z, qw, qx, qy, qz)."""
+        out = np.zeros(77)
+        self.L.orc_mesh_pose(self.h, _dp(np.ascontiguousarray(state, dtype=np.float64)), _dp(out))
+        return out.reshape(11, 7)
+
+    def mesh_traj(self, res=1000):
+        """Planner::toMeshMsg (planner.cpp:2003-2056): (parts n x 11 x 7, yaws n, arc_lengths n)."""
+        cap = res + 8
+        parts, yaws, arcs = np.zeros(cap * 77), np.zeros(cap), np.zeros(cap)
+        self.L.orc_mesh_traj.restype = C.c_int
+        n = self.L.orc_mesh_traj(self.h, C.c_int(res), C.c_int(cap), _dp(parts), _dp(yaws), _dp(arcs))
+        return parts[:n * 77].reshape(n, 11, 7), yaws[:n], arcs[:n]
+
     def traj_state(self, t):
         s = np.zeros(10)
         self.L.orc_traj_state(self.h, C.c_double(t), _dp(s))

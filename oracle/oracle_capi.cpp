@@ -161,6 +161,22 @@ int orc_car_seq(void* hh, double* seq, int cap) {
     for (int q = 0; q < 4; q++) seq[4 * k + q] = s[k][q];
   return (int)s.size();
 }
+// MomaParam::getMeshPose of one state (11 x 7) and Planner::toMeshMsg of the trajectory currently held
+void orc_mesh_pose(void* hh, const double* state10, double* parts77) {
+  double mp[11][7];
+  ((OracleHandle*)hh)->opt.robot.getMeshPose(state10, mp);
+  std::memcpy(parts77, mp, sizeof(mp));
+}
+int orc_mesh_traj(void* hh, int res, int cap, double* parts, double* yaws, double* arcs) {
+  std::vector<double> p, y, a;
+  const int n = ((OracleHandle*)hh)->opt.meshTraj(res, p, y, a);
+  for (int k = 0; k < n && k < cap; k++) {
+    std::memcpy(parts + (size_t)k * 77, p.data() + (size_t)k * 77, 77 * sizeof(double));
+    yaws[k] = y[k];
+    arcs[k] = a[k];
+  }
+  return n;
+}
 // MomaTraj::getState(t) of the trajectory currently held (10 values)
 void orc_traj_state(void* hh, double t, double* state10) {
   auto& o = ((OracleHandle*)hh)->opt;

@@ -131,6 +131,50 @@ def test_playback_matches_oracle(cuboids_small, emu_partly_solved):
             assert np.allclose(st[k], o.traj_state(float(t)), rtol=0, atol=1e-11)
 
 
+def test_mesh_poses_and_mesh_traj_match_oracle(cuboids_small, emu_partly_solved):
+    """MomaParam::getMeshPose (moma_param.h:724-790) and Planner::toMeshMsg (planner.cpp:2003-2056) of the kernel sources
+    against the oracle's restatement: random states (joints beyond their limits included: the reference clamps them),
+    then the 1000-step message of two trajectories -- same number of states, poses, yaws and arc lengths."""
+    cs, (emu, solved) = cuboids_small, emu_partly_solved
+    rng = np.random.default_rng(0)
+    st = np.concatenate([rng.uniform(-8, 8, (64, 2)), rng.uniform(-4, 4, (64, 1)), rng.uniform(-7, 7, (64, 7))], axis=1)
+    st[0] = 0.0
+    o = orc.Oracle(cs["map"])
+    pe = emu.mesh_poses(st)
+    po = np.array([o.mesh_pose(s) for s in st])
+    assert np.abs(pe - po).max() < 1e-13
+    assert np.allclose(np.linalg.norm(pe[:, :10, 3:], axis=2), 1.0, atol=1e-6)       # relative_R's 0.7071068 is not exactly orthonormal
+    assert (pe[:, 10, 3:] == 0).all() and (pe[:, 9] == pe[:, 8]).all()
+    assert np.allclose(pe[0, :, :3], [[0, 0, 0.0775], [0, 0.115, 0.0935], [0, 0.115, 0.334], [0, 0.115, 0.334], [0, 0.115, 0.59],
+                                      [0, 0.115, 0.59], [0, 0.115, 0.8], [0, 0.115, 0.8], [0, 0.115, 0.944], [0, 0.115, 0.944],
+                                      [0, 0.115, 1.1215]], atol=1e-5)   # zero pose: links stacked along z (offsets are +-1.5708, not pi/2)
+    alm = emu.alm_state()
+    for b in solved[:2]:
+        o, _ = _oracle_gate(cs["map"], cs["paths"][cs["offs"][b]:cs["offs"][b + 1]], emu.get_x(b), alm[b])
+        P, Y, A = o.mesh_traj(1000)
+        Pe, Ye, Ae = emu.mesh_traj(b, 1000)
+        assert len(Ye) == len(Y) and len(Y) in (1000, 1001)
+        assert np.abs(P - Pe).max() < 1e-11 and np.abs(Y - Ye).max() < 1e-11 and np.abs(A - Ae).max() < 1e-11
+        assert (np.diff(Ae) >= 0).all() and Ae[0] == 0.0
+
+
+@pytest.mark.gpu
+def test_mesh_traj_on_gpu_is_bit_identical_to_emulator(cuboids_small):
+    cs = cuboids_small
+    lens, paths = cs["lens"][:1], cs["paths"][:cs["offs"][1]]
+    out = {}
+    for name, lib in (("gpu", None), ("emu", EMU_LIB)):
+        p = api.default_params(api.load(lib))
+        p.s2_lbfgs.max_iterations = 20
+        p.alm_max_outer = 1
+        opt = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+        set_map(opt, cs["world"])
+        opt.optimizeTraj(lens, paths)
+        out[name] = opt.mesh_traj(0, 1000)
+    for a, b in zip(out["gpu"], out["emu"]):
+        assert a.shape == b.shape and (a == b).all()
+
+
 @pytest.mark.gpu
 def test_playback_on_gpu_is_bit_identical_to_emulator(cuboids_small):
     cs = cuboids_small

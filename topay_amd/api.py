@@ -52,6 +52,12 @@ class Params(C.Structure):
     ]
 
 
+class MeshParams(C.Structure):
+    """topay_mesh_params_t — the mesh kinematics of MomaParam (moma_param.h:60-67, 77-90, 114-115)."""
+    _fields_ = [("link_length", C.c_double * 7), ("joint_pos_limit_min", C.c_double * 7), ("joint_offset", C.c_double * 21),
+                ("joint_dof_axis", C.c_double * 21)]
+
+
 class MapDesc(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("resolution", C.c_double), ("dims", C.c_int * 3),
                 ("min_boundary", C.c_double * 3), ("max_boundary", C.c_double * 3)]
@@ -79,6 +85,9 @@ def load(path=None):
     L.topay_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
     L.topay_destroy.argtypes = [C.c_void_p]
     L.topay_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    L.topay_default_mesh_params.argtypes = [C.POINTER(MeshParams)]
+    L.topay_mesh_poses.argtypes = [C.c_void_p, C.POINTER(MeshParams), C.c_int, c_dp, c_dp]
+    L.topay_mesh_traj.argtypes = [C.c_void_p, C.c_int, C.POINTER(MeshParams), C.c_int, C.c_int, c_dp, c_dp, c_dp, c_ip]
     L.topay_set_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapDesc), c_dp, c_dp]
     L.topay_set_init_traj.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
     L.topay_reset.argtypes = [C.c_void_p]
@@ -518,6 +527,28 @@ class MomaTrajOptBatch:
         rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
         _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
         return f.value, g, e
+
+    def _mesh_params(self):
+        m = MeshParams()
+        _chk(self.L, self.L.topay_default_mesh_params(C.byref(m)))
+        return m
+
+    def mesh_poses(self, states, mesh=None):
+        """MomaParam::getMeshPose for n states: (n, 11, 7) = (x, y, z, qw, qx, qy, qz) of chassis, stump, 7 links, ee, ee point."""
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 10)
+        out = np.zeros((len(st), 11, 7))
+        m = mesh or self._mesh_params()
+        _chk(self.L, self.L.topay_mesh_poses(self.h, C.byref(m), len(st), _dp(st), _dp(out)))
+        return out
+
+    def mesh_traj(self, i, res=1000, mesh=None):
+        """Planner::toMeshMsg of candidate i: (parts (n, 11, 7), yaws (n), arc_lengths (n))."""
+        cap = res + 1
+        parts, yaws, arcs = np.zeros((cap, 11, 7)), np.zeros(cap), np.zeros(cap)
+        n = np.zeros(1, dtype=np.int32)
+        m = mesh or self._mesh_params()
+        _chk(self.L, self.L.topay_mesh_traj(self.h, i, C.byref(m), res, cap, _dp(parts), _dp(yaws), _dp(arcs), _ip(n)))
+        return parts[:n[0]], yaws[:n[0]], arcs[:n[0]]
 
     def set_params(self, params=None):
         """Push `opt_param` (or `params`) to the context: the reference's `opt_param` is a public member the planner may

@@ -332,16 +332,9 @@ __device__ __forceinline__ void playback(const FeasIO& F, int nq, const double* 
 // sampled or interpolated state (joint limits, chassis against the 2-D field, every sphere against the 3-D field,
 // spheres against the chassis top and against each other).  A point outside the map counts as a collision
 // (isCollision2d / isCollision3d, grid_map.h:511-536, 699-725).  One thread per state.
-__device__ __forceinline__ bool whole_body_collision(const DevMap& M, const double* st) {
+// MomaParam::getColliPts (moma_param.h:203-247): centres of the 12 collision spheres of state st = (x, y, theta, q1..q7)
+__device__ __forceinline__ void sphere_centres(const double* st, double (&Px)[TOPAY_NSPH], double (&Py)[TOPAY_NSPH], double (&Pz)[TOPAY_NSPH]) {
   const DevParams& P = g_P;
-  bool hit = false;
-#pragma unroll
-  for (int q = 0; q < 7; q++) hit = hit || st[3 + q] > P.joint_pos_limit_max[q] || st[3 + q] < -P.joint_pos_limit_max[q];
-  {
-    const double d = feas_dist2d(M, st[0], st[1]);   // 1e10 outside the map
-    const bool in = d < 1.0e+9;
-    hit = hit || !in || d < P.chassis_colli_radius;
-  }
   double sq[7], cq[7], sth, cth;
 #pragma unroll
   for (int q = 0; q < 7; q++) det_sincos(st[3 + q], &sq[q], &cq[q]);
@@ -358,7 +351,6 @@ __device__ __forceinline__ bool whole_body_collision(const DevMap& M, const doub
   const double p0x = st[0] + (cth * P.relT[0] - sth * P.relT[1]);
   const double p0y = st[1] + (sth * P.relT[0] + cth * P.relT[1]);
   const double p0z = P.chassis_height + P.relT[2];
-  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
   double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
   double q0 = 0.0, q1 = 0.0, q2 = 0.0;
   int sidx = 0;
@@ -379,6 +371,20 @@ __device__ __forceinline__ bool whole_body_collision(const DevMap& M, const doub
     if (li == 7) break;
     joint_rotate(R, li, cq[li], sq[li]);
   }
+}
+
+__device__ __forceinline__ bool whole_body_collision(const DevMap& M, const double* st) {
+  const DevParams& P = g_P;
+  bool hit = false;
+#pragma unroll
+  for (int q = 0; q < 7; q++) hit = hit || st[3 + q] > P.joint_pos_limit_max[q] || st[3 + q] < -P.joint_pos_limit_max[q];
+  {
+    const double d = feas_dist2d(M, st[0], st[1]);   // 1e10 outside the map
+    const bool in = d < 1.0e+9;
+    hit = hit || !in || d < P.chassis_colli_radius;
+  }
+  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
+  sphere_centres(st, Px, Py, Pz);
 #pragma unroll
   for (int i = 0; i < TOPAY_NSPH; i++) {
     const double d = feas_dist3d(M, Px[i], Py[i], Pz[i]);
@@ -394,6 +400,114 @@ __device__ __forceinline__ bool whole_body_collision(const DevMap& M, const doub
     }
   }
   return hit;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MomaParam::getMeshPose (moma_param.h:724-790), the per-state work of Planner::toMeshMsg (planner.cpp:2003-2056): poses
+// (x, y, z, qw, qx, qy, qz) of chassis, stump, 7 links, end effector (copy of the last link) and the end effector's
+// collision point (position only).  The reference composes them with Eigen's rotation types; these are Eigen's generic
+// algorithms (AngleAxis -> quaternion, quaternion product, toRotationMatrix, rotation matrix -> quaternion), written
+// out so that every state is one thread's straight-line arithmetic.
+// ---------------------------------------------------------------------------------------------------------------
+struct MeshQuat { double w, x, y, z; };
+__device__ __forceinline__ MeshQuat mq_axis(double angle, int axis) {
+  double s, c;
+  det_sincos(0.5 * angle, &s, &c);
+  MeshQuat q{c, 0.0, 0.0, 0.0};
+  if (axis == 0) q.x = s * 1.0; else if (axis == 1) q.y = s * 1.0; else q.z = s * 1.0;
+  return q;
+}
+__device__ __forceinline__ MeshQuat mq_mul(const MeshQuat& a, const MeshQuat& b) {
+  return MeshQuat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                  a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ MeshQuat mq_euler(double r, double p, double y) { return mq_mul(mq_mul(mq_axis(r, 0), mq_axis(p, 1)), mq_axis(y, 2)); }
+__device__ __forceinline__ void mq_matrix(const MeshQuat& q, double (&m)[9]) {
+  const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  m[0] = 1.0 - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy;
+  m[3] = txy + twz; m[4] = 1.0 - (txx + tzz); m[5] = tyz - twx;
+  m[6] = txz - twy; m[7] = tyz + twx; m[8] = 1.0 - (txx + tyy);
+}
+__device__ __forceinline__ MeshQuat mq_from_matrix(const double (&a)[9]) {
+  double t = a[0] + a[4] + a[8];
+  double c[4];   // x, y, z, w
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    c[3] = 0.5 * t;
+    t = 0.5 / t;
+    c[0] = (a[7] - a[5]) * t;
+    c[1] = (a[2] - a[6]) * t;
+    c[2] = (a[3] - a[1]) * t;
+  } else {
+    int i = 0;
+    if (a[4] > a[0]) i = 1;
+    if (a[8] > a[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(a[4 * i] - a[4 * j] - a[4 * k] + 1.0);
+    c[i] = 0.5 * t;
+    t = 0.5 / t;
+    c[3] = (a[3 * k + j] - a[3 * j + k]) * t;
+    c[j] = (a[3 * j + i] + a[3 * i + j]) * t;
+    c[k] = (a[3 * k + i] + a[3 * i + k]) * t;
+  }
+  return MeshQuat{c[3], c[0], c[1], c[2]};
+}
+__device__ __forceinline__ void mq_matmul(const double (&a)[9], const double (&b)[9], double (&r)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+__device__ __forceinline__ void mesh_pose(const topay_mesh_params_t& K, const double* st, double* out /* 11 x 7 */) {
+  const DevParams& P = g_P;
+  auto put = [&](int r, double px, double py, double pz, const MeshQuat& q) {
+    double* o = out + 7 * r;
+    o[0] = px; o[1] = py; o[2] = pz; o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+  };
+  double ax = st[0], ay = st[1], az = P.chassis_height / 2.0;
+  put(0, ax, ay, az, mq_euler(1.5707963267948966, st[2], 0.0));
+  MeshQuat aq;
+  {
+    double s, c;
+    det_sincos(st[2] / 2.0, &s, &c);
+    aq = MeshQuat{c, 0.0, 0.0, s};
+  }
+  double A[9], B[9];
+  mq_matrix(aq, A);
+  ax += (A[0] * P.relT[0] + A[1] * P.relT[1]) + A[2] * P.relT[2];
+  ay += (A[3] * P.relT[0] + A[4] * P.relT[1]) + A[5] * P.relT[2];
+  az += (A[6] * P.relT[0] + A[7] * P.relT[1]) + A[8] * P.relT[2];
+  {
+    double RR[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) RR[t] = P.relR[t];
+    mq_matmul(A, RR, B);
+  }
+  aq = mq_from_matrix(B);
+  put(1, ax, ay, az, aq);
+  for (int i = 0; i < 7; i++) {
+    double q = st[3 + i];
+    q = fmax(K.joint_pos_limit_min[i], fmin(P.joint_pos_limit_max[i], q));
+    mq_matrix(aq, A);
+    const double l = K.link_length[i];
+    ax += (A[0] * 0.0 + A[1] * 0.0) + A[2] * l;
+    ay += (A[3] * 0.0 + A[4] * 0.0) + A[5] * l;
+    az += (A[6] * 0.0 + A[7] * 0.0) + A[8] * l;
+    double O[9], Rq[9], AO[9];
+    mq_matrix(mq_euler(K.joint_offset[3 * i], K.joint_offset[3 * i + 1], K.joint_offset[3 * i + 2]), O);
+    mq_matrix(mq_euler(K.joint_dof_axis[3 * i] * q, K.joint_dof_axis[3 * i + 1] * q, K.joint_dof_axis[3 * i + 2] * q), Rq);
+    mq_matmul(A, O, AO);
+    mq_matmul(AO, Rq, B);
+    aq = mq_from_matrix(B);
+    put(2 + i, ax, ay, az, aq);
+  }
+  for (int c = 0; c < 7; c++) out[7 * 9 + c] = out[7 * 8 + c];
+  double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
+  sphere_centres(st, Px, Py, Pz);
+  for (int c = 0; c < 7; c++) out[7 * 10 + c] = 0.0;
+  out[70] = Px[TOPAY_NSPH - 1]; out[71] = Py[TOPAY_NSPH - 1]; out[72] = Pz[TOPAY_NSPH - 1];
 }
 
 }  // namespace topay

@@ -366,6 +366,15 @@ __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps
   feasibility_gate(F, mp);
 }
 
+// MomaParam::getMeshPose of n states, one thread per state
+__global__ void __launch_bounds__(64) k_mesh_pose(topay_mesh_params_t K, int n, const double* states, double* parts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double st[10];
+  for (int k = 0; k < 10; k++) st[k] = states[(size_t)i * 10 + k];
+  mesh_pose(K, st, parts + (size_t)i * 77);
+}
+
 // MomaTraj playback of one candidate (car_seq + getState at given times)
 __global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cseq, long long cap_panels, int nq, const double* times,
                                                  double* states, double* seq_out, int* nseq_out) {
@@ -1742,6 +1751,77 @@ topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* time
   if (n_seq) *n_seq = ns;
   if (seq && ns > 0) HIPCHK(memcpy_sync(c, seq, d_seq, (size_t)std::min(ns, seq_cap) * 4 * 8, hipMemcpyDeviceToHost));
   if (n_times) HIPCHK(memcpy_sync(c, states, d_states, (size_t)n_times * 10 * 8, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+topay_status topay_default_mesh_params(topay_mesh_params_t* p) {
+  if (!p) return TOPAY_ERR_INVALID_ARG;
+  const double ll[7] = {0.2405, 0.0, 0.256, 0.0, 0.21, 0.0, 0.144};              // moma_param.h:114
+  const double lo[7] = {-3.1, -2.26, -3.1, -2.355, -3.1, -2.23, -6.28};          // moma_param.h:115
+  for (int i = 0; i < 7; i++) {
+    p->link_length[i] = ll[i];
+    p->joint_pos_limit_min[i] = lo[i];
+    for (int k = 0; k < 3; k++) { p->joint_offset[3 * i + k] = 0.0; p->joint_dof_axis[3 * i + k] = 0.0; }
+    if (i < 6) {                                                                  // moma_param.h:77-90
+      p->joint_offset[3 * i] = (i % 2 == 0) ? -1.5708 : 1.5708;
+      p->joint_dof_axis[3 * i + 1] = (i % 2 == 0) ? -1.0 : 1.0;
+    } else {
+      p->joint_dof_axis[3 * i + 2] = 1.0;
+    }
+  }
+  return TOPAY_OK;
+}
+
+topay_status topay_mesh_poses(topay_ctx* c, const topay_mesh_params_t* mesh, int n, const double* states, double* parts) {
+  if (!c || !mesh || n < 0 || (n > 0 && (!states || !parts))) return TOPAY_ERR_INVALID_ARG;
+  if (n == 0) return TOPAY_OK;
+  HIPCHK(hipSetDevice(c->device));
+  topay_status s;
+  if ((s = c->pb_io.ensure((size_t)n * (10 + 77) * 8)) != TOPAY_OK) return s;
+  double* d_st = c->pb_io.as<double>();
+  double* d_parts = d_st + (size_t)n * 10;
+  HIPCHK(hipMemcpyAsync(d_st, states, (size_t)n * 80, hipMemcpyHostToDevice, c->stream));
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  hipLaunchKernelGGL(k_mesh_pose, dim3((n + 63) / 64), dim3(64), 0, c->stream, *mesh, n, (const double*)d_st, d_parts);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(parts, d_parts, (size_t)n * 77 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return TOPAY_OK;
+}
+
+// Planner::toMeshMsg (planner.cpp:2003-2056).  The sample times and the arc length are running sums over the samples
+// (host, in the reference's order); getState and getMeshPose of all samples run on the device.
+topay_status topay_mesh_traj(topay_ctx* c, int i, const topay_mesh_params_t* mesh, int res, int cap_states, double* parts,
+                             double* yaws, double* arc_lengths, int* n_states) {
+  if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
+  if (i < 0 || i >= c->B || !mesh || res <= 0 || cap_states < res + 1 || !parts || !yaws || !arc_lengths || !n_states) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<double> hT((size_t)c->Nmax);
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
+  double T = 0.0;
+  for (int k = 0; k < c->hN[i]; k++) T += hT[k];
+  if (!(T > 0.0 && T < 1.0e4)) { *n_states = 0; return TOPAY_OK; }
+  const double intvl = T / res;
+  std::vector<double> times;
+  for (double t = 0.0; t < T && (int)times.size() < cap_states; t += intvl) times.push_back(t);
+  const int n = (int)times.size();
+  std::vector<double> st((size_t)(n + 1) * 10);
+  times.push_back(0.0);                       // prev_state of the first sample = getState(0)
+  topay_status s = topay_playback(c, i, n + 1, times.data(), st.data(), 0, nullptr, nullptr);
+  if (s != TOPAY_OK) return s;
+  if ((s = topay_mesh_poses(c, mesh, n, st.data(), parts)) != TOPAY_OK) return s;
+  double acc = 0.0;
+  const double* prev = &st[(size_t)n * 10];
+  for (int k = 0; k < n; k++) {
+    const double* cur = &st[(size_t)k * 10];
+    const double dx = cur[0] - prev[0], dy = cur[1] - prev[1];
+    acc += std::sqrt(dx * dx + dy * dy);
+    arc_lengths[k] = acc;
+    yaws[k] = cur[2];
+    prev = cur;
+  }
+  *n_states = n;
   return TOPAY_OK;
 }
 
