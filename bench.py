@@ -3,9 +3,12 @@
 
 Workload ("benchmark_tables batch"): S independent 'tables' scenarios per GPU, each with its own freshly generated map
 (the reference's benchmark loop regenerates the map every episode, src/planner/src/planner.cpp:514-521) and 8 topological
-candidate init paths (the reference's cap, planner.cpp:59,829).  One step = the whole hot path over the batch, starting
-from inputs resident in HBM: the init kernel (optimizeTraj lines 146-357) + the persistent solve kernel (lines 359-497:
-stage-1 L-BFGS, stage-2 ALM loop) + the gather of per-scenario result records (RCCL all-gather when N > 1).
+candidate init paths (the reference's cap, planner.cpp:59,829).  One step = the whole hot path over the batch with the
+maps resident in HBM: upload of the raw init paths + the init kernel (optimizeTraj lines 146-357) + the persistent solve
+kernels (lines 359-497: stage-1 L-BFGS, stage-2 ALM loop) + the feasibility gate (planner.cpp:878-880) + download of
+flags, costs and durations, the per-scenario winner selection (planner.cpp:999-1016) and download of the winners'
+trajectories + the gather of per-scenario result records (RCCL all-gather when N > 1).  Three batches are kept in
+flight by default (--inflight); the strictly serial figures are measured in the same run and reported beside the line.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
@@ -366,8 +369,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3 (persistent solve: one workgroup per SIMD slot takes candidates from its class's queue; the "
-                      "three class launches of a batch run concurrently)",
+            "kernel": "k_solve1/2/3/4/6 (persistent solve: one workgroup per SIMD slot takes candidates from its class's queue; the "
+                      "up to five class launches of a batch run concurrently)",
             "kernel_ms": kms,
             "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else
                                      "wall time of the timed region / steps (launches of consecutive steps overlap; the event span of each "
