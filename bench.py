@@ -24,7 +24,9 @@ import sys
 import time
 
 # before anything initialises HIP (torch.cuda does): the solver's bucket streams need distinct hardware queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (three batches in flight use 15; with 16 in all the RCCL gather's stream shares a queue with a solve launch and the
+# multi-GPU path runs at half speed -- tools/ab_dist.sh: 4.5k against 9.3k trajectories/s with 20 or 24)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np
 

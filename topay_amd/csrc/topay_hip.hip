@@ -481,7 +481,9 @@ struct DevBuf {
 // mixed priorities made the hardware preempt (context-save) the low-priority waves whenever high-priority work
 // arrived, and twice in ~80 runs one low-priority launch was starved for tens of seconds.  HIP maps the streams of one
 // priority onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues shared by every stream of the process, and
-// streams that share a queue serialise (tools/queue_probe.hip); the library asks for 16 queues at load time (below)
+// streams that share a queue serialise (tools/queue_probe.hip); the library asks for 24 queues at load time (below: three contexts in
+// flight use 15, and another library's stream -- RCCL's -- that lands on the queue of a persistent solve launch waits a
+// whole solve; 32 and more are time-sliced by the scheduler firmware)
 // when the environment does not say otherwise.  With one wave per SIMD, the LDS of the three common classes (<= 20 /
 // 36 / 53 KB per wave) does not limit residency; the two rare classes of long candidates (<= 70 / 107 KB of a CU's
 // 160 KB) do cost their CU a slot or two, which is why they are kept apart from each other.
@@ -489,8 +491,8 @@ static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32, 42, TOPAY_MAX_N};
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
-// GPU_MAX_HW_QUEUES=16 itself.
-__attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// GPU_MAX_HW_QUEUES=24 itself.
+__attribute__((constructor)) static void topay_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 // Dispatch gate (topay_optimize_async): the context whose solve was issued last in this process.
 struct topay_ctx;
 static std::mutex g_issue_mutex;
