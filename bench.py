@@ -24,7 +24,7 @@ import sys
 import time
 
 # before anything initialises HIP (torch.cuda does): the solver's bucket streams need distinct hardware queues
-# (three batches in flight use 15; with 16 in all the RCCL gather's stream shares a queue with a solve launch and the
+# (three batches in flight use 18; with 16 in all the RCCL gather's stream shares a queue with a solve launch and the
 # multi-GPU path runs at half speed -- tools/ab_dist.sh: 4.5k against 9.3k trajectories/s with 20 or 24)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
@@ -68,8 +68,8 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenarios", type=int, default=1024, help="scenarios per GPU (x 8 candidates each)")
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
@@ -372,7 +372,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
             "kernel": "k_solve1/2/3/4/6 (persistent solve: one workgroup per SIMD slot takes candidates from its class's queue; the "
-                      "up to five class launches of a batch run concurrently)",
+                      "up to six class launches of a batch run concurrently)",
             "kernel_ms": kms,
             "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else
                                      "wall time of the timed region / steps (launches of consecutive steps overlap; the event span of each "

@@ -21,7 +21,7 @@ for _ in range(depth):
     opts.append(o)
 for o in opts:
     o.reset(); o.optimize()
-N = opts[0].n_pieces(); m = N > 0
+N = opts[0].n_pieces(); m = (N > 0) & (opts[0].elapsed_us() > 0)   # (candidates a diagnostic build left out have no device time)
 rec = []
 t0 = time.perf_counter()
 def fin(i):
@@ -47,7 +47,7 @@ cls = np.where(Nm <= 10, 0, np.where(Nm <= 21, 1, np.where(Nm <= 32, 2, np.where
 for (i, s_, u_, th, hw_) in rec[:8]:
     s0 = s_ - base
     print(f"  batch {i} per class (first start, queue drained = last start, last end) ms:",
-          [(int(s0[cls == k].min() / 1e3), int(s0[cls == k].max() / 1e3), int((s0 + u_)[cls == k].max() / 1e3)) for k in range(5)])
+          [(int(s0[cls == k].min() / 1e3), int(s0[cls == k].max() / 1e3), int((s0 + u_)[cls == k].max() / 1e3)) if (cls == k).any() else None for k in range(5)])
 T = max((r[1] - base + r[2]).max() for r in rec)
 nb = 40
 edges = np.linspace(0, T, nb + 1)

@@ -482,12 +482,17 @@ struct DevBuf {
 // arrived, and twice in ~80 runs one low-priority launch was starved for tens of seconds.  HIP maps the streams of one
 // priority onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues shared by every stream of the process, and
 // streams that share a queue serialise (tools/queue_probe.hip); the library asks for 24 queues at load time (below: three contexts in
-// flight use 15, and another library's stream -- RCCL's -- that lands on the queue of a persistent solve launch waits a
+// flight use 18, and another library's stream -- RCCL's -- that lands on the queue of a persistent solve launch waits a
 // whole solve; 32 and more are time-sliced by the scheduler firmware)
 // when the environment does not say otherwise.  With one wave per SIMD, the LDS of the three common classes (<= 20 /
 // 36 / 53 KB per wave) does not limit residency; the two rare classes of long candidates (<= 70 / 107 KB of a CU's
 // 160 KB) do cost their CU a slot or two, which is why they are kept apart from each other.
-static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 21, 32, 42, TOPAY_MAX_N};
+static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 15, 21, 32, 42, TOPAY_MAX_N};
+// Launch classes are finer than kernel templates where that saves LDS: the two-rows-per-lane kernel serves N <= 15 with
+// 29 KB and N <= 21 with 38 KB per workgroup (most candidates of the benchmark have 11..15 pieces).  LDS is what
+// limits how many workgroups a CU hosts beside a long candidate's: giving every class-1 workgroup the 38 KB of class 2
+// cost 8 % of the throughput, taking 9 KB from most class-2 workgroups pays the other way.
+static const int kBigFirst = TOPAY_NBUCKET - 2;   // the two classes of long candidates (72 / 106 KB of LDS)
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
@@ -860,7 +865,7 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
 }
 
 static int bucket_of(int N) {
-  // diagnostic (tests): TOPAY_FORCE_CLASS=2|3 sends every candidate that fits through the kernel with 2 | 3 rows per lane
+  // diagnostic: TOPAY_FORCE_CLASS=k sends every candidate that fits through launch class k (1-based) or a later one
   static const int force = [] { const char* f = getenv("TOPAY_FORCE_CLASS"); return f ? atoi(f) : 0; }();
   int k0 = 0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
@@ -1294,10 +1299,10 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   // other way round): the longest class first gets one workgroup per candidate as far as the pool goes, so that no
   // 43..64-piece candidate -- the longest single solves of a batch -- queues behind another one.
   static const bool pool_big = [] { const char* e = getenv("TOPAY_BIG_POOL"); return e && e[0] == '1'; }();
-  if (pool_big && topay_ctx::NBUCKET == 5 && share[4] > 0) {
-    const int pool = share[3] + share[4], n3 = (int)c->cls[3].size(), n4 = (int)c->cls[4].size();
-    share[4] = std::min(n4, pool - (n3 > 0 ? 1 : 0));
-    share[3] = std::min(n3, pool - share[4]);
+  if (pool_big && share[kBigFirst + 1] > 0) {
+    const int pool = share[kBigFirst] + share[kBigFirst + 1], n3 = (int)c->cls[kBigFirst].size(), n4 = (int)c->cls[kBigFirst + 1].size();
+    share[kBigFirst + 1] = std::min(n4, pool - (n3 > 0 ? 1 : 0));
+    share[kBigFirst] = std::min(n3, pool - share[kBigFirst + 1]);
   }
 }
 
@@ -1306,9 +1311,9 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
 // candidate actually in the class.
 typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
 typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
-static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve3, k_solve4, k_solve6};
-static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain3, k_chain4, k_chain6};
-static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval3, k_eval4, k_eval6};
+static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve2, k_solve3, k_solve4, k_solve6};
+static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain2, k_chain3, k_chain4, k_chain6};
+static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval2, k_eval3, k_eval4, k_eval6};
 
 // Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most its class can ask
 // for (the launch itself passes the size it needs), not per launch: two host threads launching different contexts
@@ -1364,7 +1369,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
       // the two classes of long candidates (70 / 107 KB of LDS, a CU has 160 KB for its four SIMDs) only with each
       // other's: while they are resident their CU cannot fill its other SIMDs, so they should leave as soon as the
       // long candidates are done and make room for workgroups (of the next batch) that need a quarter of that.
-      d.queue_lowest = c->steal ? (k >= 3 ? 3 : 0) : k;
+      d.queue_lowest = c->steal ? (k >= kBigFirst ? kBigFirst : 0) : k;
       int o2 = 0;
       for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {   // `order` holds the classes largest first
         d.queue_off[kk] = o2;
@@ -1628,14 +1633,14 @@ topay_status topay_optimize_async(topay_ctx* c) {
     int nl = 0, ng = 0;
     for (int k = 0; k < topay_ctx::NBUCKET; k++) {
       nl += (int)c->cls[k].size();
-      if (k <= 2) ng += (int)c->cls[k].size();
+      if (k < kBigFirst) ng += (int)c->cls[k].size();
     }
     c->n_launched = nl;
     // The gate waits for the candidates of the three common classes only: the few workgroups of the two classes of
     // long candidates need 70 / 107 KB of LDS and may not find a compute unit with that much free until the previous
     // batch's tail -- holding the whole next batch back for them leaves the rest of the device idle meanwhile.
     c->n_gate = ng;
-    c->db.gate_maxN = kBucketMaxN[2];
+    c->db.gate_maxN = kBucketMaxN[kBigFirst - 1];
     void* dp = nullptr;
     HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
     c->db.started = (int*)dp;

@@ -11,7 +11,7 @@
 // <= 32 three, <= 42 four, <= 64 six.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer candidates are
 // reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them as n_not_launched).
 #define TOPAY_MAX_N 64
-#define TOPAY_NBUCKET 5
+#define TOPAY_NBUCKET 6
 #define TOPAY_WAVE 64
 
 // Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
