@@ -137,7 +137,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   EvalCtx C;
   load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8] past costs, then [256] two-loop alpha
+  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8] past costs, then [48] solver state parked across an evaluation
   SolveIO S;
   S.x = (glb_dp)(Bt.x + (size_t)b * Bt.nmax);
   S.g = (glb_dp)(Bt.work + ((size_t)b * 4 + 0) * Bt.nmax);
@@ -875,7 +875,7 @@ static int bucket_of(int N) {
   return k0;
 }
 // + past-cost ring [8] + two-loop alpha ring [256] + the solver state parked across an evaluation [48]
-static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 256 + 48) * sizeof(double); }
+static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 48) * sizeof(double); }
 
 static bool batch_done(topay_ctx* p);
 // what the __constant__ parameter block of each device holds (last push)

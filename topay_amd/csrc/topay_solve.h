@@ -85,7 +85,7 @@ __device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane)
 
 template <int RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8 + 256 + 48] */, int& success_out, double& cost_out) {
+                                                 lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out) {
   const DevParams& P = g_P;
   const int lane = C.lane, n = __builtin_amdgcn_readfirstlane(C.n);
   constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
@@ -135,7 +135,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     // what is live across a call would otherwise be spilled to scratch memory): every lane writes the same values to
     // the same words and reads them back afterwards.
     {
-      lds_dp pk = pf + 8 + 256;
+      lds_dp pk = pf + 8;
       pk[0] = fx; pk[1] = step; pk[2] = stp; pk[3] = finit; pk[4] = dginit; pk[5] = dgtest; pk[6] = dstest; pk[7] = mu;
       pk[8] = nu; pk[9] = cost;
       TOPAY_LDS int* ik = (TOPAY_LDS int*)(pk + 10);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     else f = eval_cost_grad<2, RMAX>(C, mp, gate);
     {
       // (read back as wave-uniform values: scalar registers, scalar branches, scalar base addresses for the vector loads)
-      lds_cdp pk = pf + 8 + 256;
+      lds_cdp pk = pf + 8;
       fx = uniform_f64(pk[0]); step = uniform_f64(pk[1]); stp = uniform_f64(pk[2]); finit = uniform_f64(pk[3]);
       dginit = uniform_f64(pk[4]); dgtest = uniform_f64(pk[5]); dstest = uniform_f64(pk[6]); mu = uniform_f64(pk[7]);
       nu = uniform_f64(pk[8]); cost = uniform_f64(pk[9]);
@@ -359,7 +359,10 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
               for (int t = 0; t < EPL; t++) dr[t] = vec_in(lane, t, n) ? -gv[t] : 0.0;
             }
             double sb[PF][EPL], yb[PF][EPL], rb[PF];
-            lds_dp alpha = pf + 8;  // [mem <= 256]: every lane writes / reads the same entry (LDS broadcast)
+            // [mem <= 256]: every lane writes / reads the same entry (LDS broadcast).  The ring lives in the evaluation's
+            // scratch region (band / pass buffers, >= 960 doubles): nothing of an evaluation stays there between two calls,
+            // and the recursion runs between them -- 2 KB less LDS per workgroup.
+            lds_dp alpha = C.X;
             // wave-uniform loop state in scalar registers (the values are uniform by construction; the compiler only
             // sees that they were derived from vector compares)
             const int endu = __builtin_amdgcn_readfirstlane(end), boundu = __builtin_amdgcn_readfirstlane(bound);
