@@ -484,14 +484,14 @@ struct DevBuf {
 // streams that share a queue serialise (tools/queue_probe.hip); the library asks for 24 queues at load time (below: three contexts in
 // flight use 18, and another library's stream -- RCCL's -- that lands on the queue of a persistent solve launch waits a
 // whole solve; 32 and more are time-sliced by the scheduler firmware)
-// when the environment does not say otherwise.  With one wave per SIMD, the LDS of the three common classes (<= 20 /
-// 36 / 53 KB per wave) does not limit residency; the two rare classes of long candidates (<= 70 / 107 KB of a CU's
-// 160 KB) do cost their CU a slot or two, which is why they are kept apart from each other.
+// when the environment does not say otherwise.  With one wave per SIMD, four workgroups of the common classes (<= 21 /
+// 27 / 36 / 54 KB per wave) share a CU's 160 KB; the two rare classes of long candidates (<= 70 / 104 KB) cost their CU a
+// slot or two, which is why they are kept apart from each other.
 static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 15, 21, 32, 42, TOPAY_MAX_N};
 // Launch classes are finer than kernel templates where that saves LDS: the two-rows-per-lane kernel serves N <= 15 with
-// 29 KB and N <= 21 with 38 KB per workgroup (most candidates of the benchmark have 11..15 pieces).  LDS is what
+// 27 KB and N <= 21 with 36 KB per workgroup (most candidates of the benchmark have 11..15 pieces).  LDS is what
 // limits how many workgroups a CU hosts beside a long candidate's: giving every class-1 workgroup the 38 KB of class 2
-// cost 8 % of the throughput, taking 9 KB from most class-2 workgroups pays the other way.
+// cost 8 % of the throughput, taking 9 KB from most of the two-rows workgroups pays the other way.
 static const int kBigFirst = TOPAY_NBUCKET - 2;   // the two classes of long candidates (72 / 106 KB of LDS)
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
@@ -1366,7 +1366,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
       d.queue_next = c->qnext.as<int>();
       d.queue_class = k;
       // A workgroup whose own queue is empty goes on with the queues of the smaller classes -- but the workgroups of
-      // the two classes of long candidates (70 / 107 KB of LDS, a CU has 160 KB for its four SIMDs) only with each
+      // the two classes of long candidates (70 / 104 KB of LDS, a CU has 160 KB for its four SIMDs) only with each
       // other's: while they are resident their CU cannot fill its other SIMDs, so they should leave as soon as the
       // long candidates are done and make room for workgroups (of the next batch) that need a quarter of that.
       d.queue_lowest = c->steal ? (k >= kBigFirst ? kBigFirst : 0) : k;
@@ -1637,7 +1637,7 @@ topay_status topay_optimize_async(topay_ctx* c) {
     }
     c->n_launched = nl;
     // The gate waits for the candidates of the three common classes only: the few workgroups of the two classes of
-    // long candidates need 70 / 107 KB of LDS and may not find a compute unit with that much free until the previous
+    // long candidates need 70 / 104 KB of LDS and may not find a compute unit with that much free until the previous
     // batch's tail -- holding the whole next batch back for them leaves the rest of the device idle meanwhile.
     c->n_gate = ng;
     c->db.gate_maxN = kBucketMaxN[kBigFirst - 1];
