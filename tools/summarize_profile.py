@@ -76,14 +76,19 @@ def main(src, dst, tag, suffix=""):
             out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {(r[2] - t0) / 1e6:.1f} | {(r[3] - t0) / 1e6:.1f} | {r[4] / 1e6:.1f} | {r[5] // 64} |")
         ends = sorted(r[3] for r in rows2)
         # one step = one launch per class, issued together; the step's end = its last launch's end
-        per = len({r[0] for r in rows2})
-        by_step = [max(r[3] for r in rows2[i:i + per]) for i in range(0, len(rows2) - len(rows2) % per, per)]
+        groups = []   # the launches of a step start within a few ms of each other
+        for r in rows2:
+            if groups and r[2] - groups[-1][0][2] < 5e6:
+                groups[-1].append(r)
+            else:
+                groups.append([r])
+        by_step = [max(r[3] for r in g) for g in groups]
         if len(by_step) > 2:
             cad = [(b - a) / 1e6 for a, b in zip(by_step[1:-1], by_step[2:])]
             out.append("")
             out.append(f"- time between the ends of consecutive timed steps: {', '.join(f'{c:.0f}' for c in cad)} ms "
                        f"(mean {sum(cad) / len(cad):.0f}; negative = a step whose long-candidate launch ended before the previous step's)")
-            sts = [min(r[2] for r in rows2[i:i + per]) for i in range(0, len(rows2) - len(rows2) % per, per)]
+            sts = [g[0][2] for g in groups]
             out.append(f"- time between the starts of consecutive steps: {', '.join(f'{(b - a) / 1e6:.0f}' for a, b in zip(sts[1:-1], sts[2:]))} ms")
         try:
             b = json.loads(open(os.path.join(src, "bench_kt2.json")).read().strip().splitlines()[-1])
