@@ -211,6 +211,25 @@ class Oracle:
         n = self.L.orc_mesh_traj(self.h, C.c_int(res), C.c_int(cap), _dp(parts), _dp(yaws), _dp(arcs))
         return parts[:n * 77].reshape(n, 11, 7), yaws[:n], arcs[:n]
 
+    def optimize_device_order(self, eval_fn, epl=12):
+        """This restatement's solver logic with the vector arithmetic in the device's order and the cost / gradient from
+        `eval_fn(stage, x, lam, rho) -> (f, g, fxe)` (the device's evaluation hook): must reproduce a device solve bit for
+        bit.  Returns success."""
+        CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+        def cb(_user, stage, n, x, lam, rho, g, fxe):
+            xv = np.ctypeslib.as_array(x, shape=(n,)).copy()
+            f, gv, e = eval_fn(stage, xv, [lam[0], lam[1]], [rho[0], rho[1]])
+            np.ctypeslib.as_array(g, shape=(n,))[:] = gv
+            fxe[0], fxe[1] = float(e[0]), float(e[1])
+            return float(f)
+
+        self._cb = CB(cb)
+        self.L.orc_optimize_device_order.restype = C.c_int
+        self.L.orc_optimize_device_order.argtypes = [C.c_void_p, C.c_int, CB, C.c_void_p]
+        return bool(self.L.orc_optimize_device_order(self.h, epl, self._cb, None))
+
     def traj_state(self, t):
         s = np.zeros(10)
         self.L.orc_traj_state(self.h, C.c_double(t), _dp(s))

@@ -123,6 +123,20 @@ void orc_get_coeffs(void* hh, double* c, double* T) {
 }
 
 int orc_optimize(void* hh) { return ((OracleHandle*)hh)->opt.optimize() ? 1 : 0; }
+// Test tooling: this restatement's solver logic (L-BFGS, line search, ALM loop) with its vector arithmetic in the device's
+// order (epl = elements per lane, 12 covers every class) and the cost / gradient supplied by `fn` -- the device's
+// evaluation hook.  A device solve must come out bit for bit (tests/test_gpu_parity.py).
+int orc_optimize_device_order(void* hh, int epl, TrajOpt::ExternalEval fn, void* user) {
+  TrajOpt& o = ((OracleHandle*)hh)->opt;
+  o.ext_eval = fn;
+  o.ext_user = user;
+  g_device_epl = epl;
+  const bool ok = o.optimize();
+  g_device_epl = 0;
+  o.ext_eval = nullptr;
+  o.ext_user = nullptr;
+  return ok ? 1 : 0;
+}
 // stage-2 ALM loop only, from the current x and (lambda, rho) (orc_set_x / orc_set_alm)
 int orc_optimize_warm(void* hh) { return ((OracleHandle*)hh)->opt.optimize(true) ? 1 : 0; }
 // optimize with a trace of f at every evaluation; returns number of evaluations recorded (<= cap)

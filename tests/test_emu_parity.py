@@ -353,3 +353,30 @@ def test_persistent_queue_loop_in_the_emulator(cuboids_small, monkeypatch):
     # the three copies of every candidate are identical too (a workgroup's LDS state does not leak into its next candidate)
     for k in range(6):
         assert (x1[k] == x1[k + 6]).all() and (x1[k] == x1[k + 12]).all() and c1[k] == c1[k + 6] == c1[k + 12]
+
+
+def test_converged_solve_equals_oracle_solver_in_device_order(cuboids_small):
+    """Converged parity against independent solver code.  Converged values of two implementations cannot be compared
+    through the reference-order arithmetic (rounding differences are amplified).  But the solve is
+    two layers: the evaluation (checked per call against the oracle, 1e-12) and the solver logic around it -- L-BFGS,
+    Lewis-Overton line search, stop tests, ALM updates.  Here the ORACLE's solver logic (its restatement of lbfgs.hpp and
+    of optimizeTraj:359-497, not the kernel sources) runs with its vector arithmetic in the device's summation order and
+    takes cost / gradient from the evaluation hook of the kernel sources: the full solve to convergence must come out
+    bit for bit -- iterate, cost, multipliers, every counter."""
+    cs = cuboids_small
+    lens, paths = cs["lens"][:1], cs["paths"][:cs["offs"][1]]
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    ok = emu.optimizeTraj(lens, paths)
+    st, x, cost, alm = emu.stats()[0], emu.get_x(0), emu.traj_cost[0], emu.alm_state()[0]
+    ev = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(ev, cs["world"])
+    ev.set_init_traj(lens, paths)
+    o = orc.Oracle(cs["map"])
+    o.set_init_traj(paths)
+    okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, 0, xx, lam, rho))
+    so = o.stats()
+    assert okh == bool(ok[0]) and st[4] > 100          # a real solve: more than a hundred stage-2 iterations
+    assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
+            so["alm_outer"], so["sum_bound"]] == list(st)
+    assert (o.get_x() == x).all() and o.traj_cost() == cost and (o.alm_state() == alm).all()

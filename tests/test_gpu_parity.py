@@ -317,6 +317,76 @@ def test_config2_tables_64_candidates():
     assert np.mean(dev) >= np.mean(ref) - 0.15 and np.mean(dev) > 0.4, (np.mean(dev), np.mean(ref))
 
 
+def test_converged_solves_equal_oracle_solver_in_device_order():
+    """BASELINE configs[1] (one tables scenario x 64 candidates), converged parity against independent solver code: the
+    oracle's own L-BFGS / line search / ALM logic, its vector arithmetic carried out in the device's summation order,
+    fed with the device's cost and gradient through topay_eval, must reproduce every device solve bit for bit --
+    iterates, costs, multipliers and counters of all 64 candidates, whatever their status.  (The evaluation layer itself
+    is compared per call with the oracle's at 1e-11 in the tests above; see tests/test_emu_parity.py for the reasoning.)"""
+    world, start, goal, lens, paths = wl.tables_scenario(0, 64)
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, world)
+    ok = opt.optimizeTraj(lens, paths)
+    st, cost, alm = opt.stats(), opt.traj_cost.copy(), opt.alm_state()
+    xs = [opt.get_x(b) for b in range(len(lens))]
+    ev = api.MomaTrajOptBatch(device=0)
+    set_map(ev, world)
+    ev.set_init_traj(lens, paths)
+    m = orc.MapView(world.origin, world.res, world.dims, world.min_b, world.max_b, world.esdf2d, world.esdf3d)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    iters = 0
+    for b in range(len(lens)):
+        o = orc.Oracle(m)
+        o.set_init_traj(paths[offs[b]:offs[b + 1]])
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        so = o.stats()
+        assert okh == bool(ok[b]), b
+        assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
+                so["alm_outer"], so["sum_bound"]] == list(st[b]), b
+        assert (o.get_x() == xs[b]).all() and (o.alm_state() == alm[b]).all(), b
+        if ok[b]:
+            assert o.traj_cost() == cost[b], b
+        iters += int(st[b][4])
+    print(f"64 candidates, {iters} stage-2 iterations in all: device solves == oracle solver logic in device order, bit for bit")
+
+
+def test_converged_solves_of_a_benchmark_slice_equal_oracle_solver_in_device_order():
+    """The same on a slice of the headline batch (BASELINE configs[2]): the first 32 scenarios x 8 candidates of
+    bench.py's seed-42 batch, one map each, all launch classes that occur -- 256 device solves against the oracle's solver
+    logic in device order, bit for bit."""
+    tb = wl.TablesBatch(32, 8, base_seed=42, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    ev = api.MomaTrajOptBatch(device=0)
+    for k, s_ in enumerate(tb.scenarios):
+        set_map(opt, tb.world(s_), map_id=k)
+        set_map(ev, tb.world(s_), map_id=k)
+    slot = {s_: k for k, s_ in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s_] for s_ in tb.scen], dtype=np.int32)
+    ok = opt.optimizeTraj(tb.lens, tb.paths, map_ids=map_ids)
+    st, cost, alm, Np = opt.stats(), opt.traj_cost.copy(), opt.alm_state(), opt.n_pieces()
+    ev.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    views = {}
+    iters, same = 0, 0
+    for b in range(len(tb.lens)):
+        sc = tb.scen[b]
+        if sc not in views:
+            w = tb.world(sc)
+            views[sc] = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
+        o = orc.Oracle(views[sc])
+        o.set_init_traj(tb.paths[offs[b]:offs[b + 1]])
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        so = o.stats()
+        assert okh == bool(ok[b]), b
+        assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
+                so["alm_outer"], so["sum_bound"]] == list(st[b]), b
+        assert (o.get_x() == opt.get_x(b)).all() and (o.alm_state() == alm[b]).all(), b
+        iters += int(st[b][4])
+        same += 1
+    print(f"{same} candidates (pieces {Np.min()}..{Np.max()}), {iters} stage-2 iterations: device == oracle solver logic in device order, bit for bit")
+    tb.close()
+
+
 def test_large_batch_properties_and_multi_map():
     """Size-independent properties on a larger multi-map batch (32 tables scenarios x 8 candidates, one map each)."""
     tb = wl.TablesBatch(32, 8, base_seed=1000, nthreads=8)
