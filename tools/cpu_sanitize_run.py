@@ -20,3 +20,17 @@ o2.optimizeTraj(lens1, paths1)
 print("tables ok", o2.stats()[:, :3].tolist())
 st = np.zeros((4, 10)); st[:, 0] = np.linspace(-3, 3, 4)
 print("wb", o2.whole_body_collision(st))
+# output formats and front-end slice: mesh poses / MeshTraj, batched getTraj, PolyTraj layout, dense path, edge check,
+# all five fields, per-term costs through topay_set_params
+best = np.nonzero(opt.traj_cost == opt.traj_cost)[0][:2].astype(np.int32)
+if len(best):
+    print("getTrajs", len(opt.getTrajs(best)))
+    print("mesh traj", [a.shape for a in opt.mesh_traj(int(best[0]), 200)])
+    print("polytraj", len(opt.polytraj_msg(int(best[0]))))
+rng = np.random.default_rng(0)
+print("mesh poses", opt.mesh_poses(np.concatenate([rng.uniform(-8, 8, (9, 3)), rng.uniform(-7, 7, (9, 7))], axis=1)).shape)
+print("terms", sorted(opt.cost_terms(0, opt.get_x(0), [0.1, 0.2], [1e4, 1e4]).items())[:2])
+o2.build_esdf_fields(w1.origin, w1.res, w1.dims, w1.min_b, w1.max_b, w1.occ2d, None, w1.occ3d)
+print("fields", [f.shape for f in o2.get_map_fields(0)[:4]])
+raw = np.array([[0.0, 0.0], [1.0, 0.2], [2.5, 1.0], [2.6, 3.0]])
+print("dense", np.asarray(o2.dense_path([raw], [0.3], [1.0])[0]).shape)
