@@ -2,7 +2,7 @@
 # A/B of two builds on one box: TOPAY_LIB=tools/libs/libtopay_base.so against the in-tree library
 run() { tag=$1; shift; timeout -s KILL 300 "$@" > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err; python3 tools/pj.py "$tag" < gpurun_out/ab_$tag.json || tail -3 gpurun_out/ab_$tag.err; }
 A="--steps 16 --warmup 3 --no-cpu-baseline --no-config1"
-B=$PWD/tools/libs/libtopay_base.so
+B=$PWD/tools/libs/${ABLIB:-libtopay_base.so}
 echo "== long candidates alone: base"; TOPAY_LIB=$B true
 echo "== long candidates alone: new";  true
 run base1 env TOPAY_LIB=$B python3 bench.py $A
