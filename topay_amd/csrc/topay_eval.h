@@ -557,10 +557,13 @@ __device__ __noinline__ void minco_generate(EvalCtx& C) {
   }
   for (int t = lane; t < 9 * (N - 1); t += 64) {
     const int i = t / 9, d = t - 9 * i;
+    // (joint index clamped instead of d - 2: the compiler may turn the branches into selects and issue the loads for
+    // every lane, and with a uniform base plus a 32-bit lane offset a negative index is an address 4 GB away)
+    const int dq = d >= 2 ? d - 2 : 0;
     double v;
     if (d == 0) v = Theta[i];
     else if (d == 1) v = Arc[i];
-    else v = sigmoidC2(Vq[i * 7 + d - 2], P.joint_pos_limit_max[d - 2]);
+    else v = sigmoidC2(Vq[i * 7 + dq], P.joint_pos_limit_max[dq]);
     cL[d * rows + 6 * i + 5] = v;
   }
   lds_sync();
@@ -1665,9 +1668,10 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   for (int t = lane; t < 9 * (N - 1); t += 64) {
     const int i = t / 9, d = t - 9 * i;
     const double gp = adj[d * rows + 6 * i + 5];  // gdP.col(i) = adjGrad.row(6i+5)
+    const int dq = d >= 2 ? d - 2 : 0;            // clamped for the same reason as in minco_generate
     if (d == 0) c_g[N + i] = gp;
     else if (d == 1) c_g[2 * N - 1 + i] = gp;
-    else c_g[3 * N - 1 + 7 * i + (d - 2)] = gp * dQdVq(Vq[7 * i + d - 2], P.joint_pos_limit_max[d - 2]);
+    else c_g[3 * N - 1 + 7 * i + dq] = gp * dQdVq(Vq[7 * i + dq], P.joint_pos_limit_max[dq]);
   }
   if (lane == 0) c_g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
   __syncthreads();  // g (global memory) becomes visible to the lanes that read it next
