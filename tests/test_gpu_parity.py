@@ -451,6 +451,21 @@ def test_config5_high_resolution_esdf():
         assert abs(f - fg) <= 1e-11 * abs(f) and np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
     ok = opt.optimize()
     assert ok.mean() >= 0.5 and np.isfinite(opt.traj_cost[ok]).all()
+    # converged parity on the map no cache holds: the oracle's solver logic in device order, fed with the device's
+    # evaluations, reproduces the device's solves bit for bit (see test_converged_solves_equal_oracle_solver_in_device_order)
+    st, alm = opt.stats(), opt.alm_state()
+    xs = [opt.get_x(b) for b in range(len(lens))]
+    ev = api.MomaTrajOptBatch(device=0)
+    set_map(ev, w)
+    ev.set_init_traj(lens, paths)
+    for b in range(0, len(lens), 4):
+        oh = orc.Oracle(m)
+        oh.set_init_traj(paths[offs[b]:offs[b + 1]])
+        okh = oh.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        so = oh.stats()
+        assert okh == bool(ok[b]) and (oh.get_x() == xs[b]).all() and (oh.alm_state() == alm[b]).all(), b
+        assert [so["stage1_iters"], so["stage1_evals"], so["stage2_iters"], so["stage2_evals"], so["alm_outer"]] == \
+            [st[b][1], st[b][2], st[b][4], st[b][5], st[b][6]], b
     w.close()
 
 
