@@ -214,6 +214,56 @@ __global__ void k_edt_tile(int n, int W, long long step, long long inner_tiles, 
   }
 }
 
+// Final pass of a signed field in one go: the squared distances of the positive and of the negative part (two int32
+// volumes from the passes before) are both staged, both scanned, and the field  res sqrt(d+) - (res sqrt(d-) - res)  is
+// written once -- the same operations in the same order as the two separate final passes (edt_store), without the
+// read-modify-write of the double field in between.  LDS: two tiles [n][W].
+__global__ void k_edt_tile_signed(int n, int W, long long step, long long inner_tiles, long long outer_stride, long long map_stride,
+                                  const int* src_pos, const int* src_neg, double* dst_d, double res) {
+  int* tp = (int*)TOPAY_EDT_LDS;   // [n][W]
+  int* tn = tp + n * W;
+  const long long t = blockIdx.x;
+  const long long base = (long long)blockIdx.y * map_stride + (t / inner_tiles) * outer_stride + (t % inner_tiles) * W;
+  const int cells = n * W;
+  const int q0 = (int)threadIdx.x / W, l0 = (int)threadIdx.x - q0 * W, dq = (int)blockDim.x / W, dl = (int)blockDim.x - dq * W;
+  int q = q0, l = l0;
+  for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+    const long long a = base + (long long)q * step + l;
+    tp[c] = src_pos[a];
+    tn[c] = src_neg[a];
+    q += dq; l += dl;
+    if (l >= W) { l -= W; q++; }
+  }
+  __syncthreads();
+  q = q0; l = l0;
+  for (int c = threadIdx.x; c < cells; c += blockDim.x, q += dq, l += dl) {
+    if (l >= W) { l -= W; q++; }
+    int bp = tp[c], bn = tn[c];
+    for (int r = 1; r < n; r++) {
+      const int rr = r * r;
+      if (rr >= bp && rr >= bn) break;
+      const bool lo = q - r >= 0, hi = q + r < n;
+      if (!lo && !hi) break;
+      if (lo) {
+        const int vp = rr + tp[c - r * W], vn = rr + tn[c - r * W];
+        bp = vp < bp ? vp : bp;
+        bn = vn < bn ? vn : bn;
+      }
+      if (hi) {
+        const int vp = rr + tp[c + r * W], vn = rr + tn[c + r * W];
+        bp = vp < bp ? vp : bp;
+        bn = vn < bn ? vn : bn;
+      }
+    }
+    const double vp = bp >= TOPAY_EDT_INF ? TOPAY_EDT_DMAX : (double)bp;
+    const double vn = bn >= TOPAY_EDT_INF ? TOPAY_EDT_DMAX : (double)bn;
+    double out = res * sqrt(vp);
+    const double dn = res * sqrt(vn);
+    if (dn > 0.0) out += (-dn + res);
+    dst_d[base + (long long)q * step + l] = out;
+  }
+}
+
 // Seeds of the "inflate" fields (grid_map.cpp:283-300, 355-372): a cell is occupied when the field it is derived from
 // is below the chassis radius there.
 __global__ void k_edt_threshold(const double* field, double thr, signed char* occ, long long n) {

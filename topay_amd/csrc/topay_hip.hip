@@ -1008,23 +1008,33 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
                        (const signed char*)nullptr, src, dst_i, dst_d, pass, res);
     return TOPAY_OK;
   };
+  // final pass of a signed field, both signs at once (k_edt_tile_signed: two tiles of W <= 32 lines in LDS)
+  auto pick_w32 = [](long long lines) { int w = 1; for (int d = 1; d <= 32; d++) if (lines % d == 0) w = d; return w; };
+  auto signed_x = [&](long long n_elems, int n, int W, long long step, long long inner_tiles, long long outer_stride, long long tiles,
+                      const int* sp, const int* sn, double* dst_d) {
+    const size_t lb = (size_t)n * W * sizeof(int) * 2;
+    hipLaunchKernelGGL(k_edt_tile_signed, dim3((unsigned)tiles, (unsigned)n_maps), dim3(256), lb, c->stream, n, W, step, inner_tiles, outer_stride,
+                       n_elems, sp, sn, dst_d, res);
+  };
   if (small_lines) {
     // (tiles of up to 512 x 64 cells x 4 B = 128 KB of LDS: above the 64 KB default; set once, not per launch)
     static std::once_flag edt_attr_once[16];
     std::call_once(edt_attr_once[c->device % 16], [] {
       (void)hipFuncSetAttribute((const void*)k_edt_tile<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 4);
       (void)hipFuncSetAttribute((const void*)k_edt_tile<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 64 * 4);
+      (void)hipFuncSetAttribute((const void*)k_edt_tile_signed, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 4 * 2);
     });
-    const int wy = pick_w(nz), wx = pick_w((long long)ny * nz);
-    for (int pass = 0; pass < 2; pass++) {   // 3-D: along z, y, x — grid_map.cpp:425-521
+    const int wy = pick_w(nz), wx = pick_w32((long long)ny * nz);
+    int* i2n = i2 + M * n3;   // second half of the workspace volume: the negative part's squared distances after the y pass
+    for (int pass = 0; pass < 2; pass++) {   // 3-D: along z and y per sign, then along x for both — grid_map.cpp:425-521
       const dim3 g1((unsigned)((n3 + 255) / 256), (unsigned)n_maps);
       if (nz == 16) hipLaunchKernelGGL(k_edt_first_ballot<16>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
       else if (nz == 32) hipLaunchKernelGGL(k_edt_first_ballot<32>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
       else if (nz == 64) hipLaunchKernelGGL(k_edt_first_ballot<64>, g1, dim3(256), 0, c->stream, (long long)n3, (long long)n3, (const signed char*)d_occ3, i1, pass);
       else direct(k_edt_direct<0, 0>, (long long)n3, nz, d_occ3, nullptr, i1, nullptr, pass);
-      if ((s = tile(k_edt_tile<1, 0>, (long long)n3, ny, wy, nz, nz / wy, (long long)ny * nz, (long long)nx * (nz / wy), i1, i2, nullptr, pass)) != TOPAY_OK) return s;
-      if ((s = tile(k_edt_tile<1, 1>, (long long)n3, nx, wx, (long long)ny * nz, ((long long)ny * nz) / wx, 0, ((long long)ny * nz) / wx, i2, nullptr, e3, pass)) != TOPAY_OK) return s;
+      if ((s = tile(k_edt_tile<1, 0>, (long long)n3, ny, wy, nz, nz / wy, (long long)ny * nz, (long long)nx * (nz / wy), i1, pass == 0 ? i2 : i2n, nullptr, pass)) != TOPAY_OK) return s;
     }
+    signed_x((long long)n3, nx, wx, (long long)ny * nz, ((long long)ny * nz) / wx, 0, ((long long)ny * nz) / wx, i2, i2n, e3);
   }
   for (int pass = 0; pass < 2 && !small_lines; pass++) {
     // 3-D: along z (lines (x, y)), along y (lines (x, z)), along x (lines (y, z)) — grid_map.cpp:425-521
@@ -1039,12 +1049,11 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   // grid_map.cpp:125-207 and, with other seeds, 211-279, 283-351, 355-423
   auto field2d = [&](const signed char* occ, double* out) -> topay_status {
     if (small_lines) {
-      const int w2 = pick_w(ny);
-      for (int pass = 0; pass < 2; pass++) {
-        topay_status s2;
-        direct(k_edt_direct<0, 0>, (long long)n2, ny, occ, nullptr, i1, nullptr, pass);
-        if ((s2 = tile(k_edt_tile<1, 1>, (long long)n2, nx, w2, ny, ny / w2, 0, ny / w2, i1, nullptr, out, pass)) != TOPAY_OK) return s2;
-      }
+      const int w2 = pick_w32(ny);
+      int* i1n = i1 + M * n2;
+      direct(k_edt_direct<0, 0>, (long long)n2, ny, occ, nullptr, i1, nullptr, 0);
+      direct(k_edt_direct<0, 0>, (long long)n2, ny, occ, nullptr, i1n, nullptr, 1);
+      signed_x((long long)n2, nx, w2, ny, ny / w2, 0, ny / w2, i1, i1n, out);
       return TOPAY_OK;
     }
     EdtPass qy{(long long)nx, ny, (long long)nx, 0, (long long)ny, 1, 0, 0};
