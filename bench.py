@@ -74,10 +74,6 @@ def main():
     ap.add_argument("--candidates", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chain", action="store_true",
-                    help="opt-in batch chaining (TOPAY_CHAIN=1): resident workgroups go on with the next published batch instead of "
-                         "exiting; three batches in flight unless --inflight says otherwise; the record gathers of a multi-GPU run are "
-                         "deferred to the end of the timed region (nothing else runs on a device while a chain lives)")
     ap.add_argument("--no-serial", action="store_true", help="skip the strictly serial steps measured beside a pipelined run")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] latency figure (profiling runs)")
     ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
@@ -140,9 +136,6 @@ def main():
     B = len(tb.lens)
     # `--inflight` contexts hold the same batch (in a sweep they would hold consecutive batches): step i runs on context
     # i mod inflight, so the tail of one step -- a few long candidates, most SIMDs idle -- overlaps the bulk of the next.
-    if args.chain:
-        os.environ["TOPAY_CHAIN"] = "1"
-    chain = os.environ.get("TOPAY_CHAIN") == "1"
     if args.inflight is None:
         args.inflight = 3   # measured on one box (tools/ab_inflight.sh): 2 -> 7.9k, 3 -> 8.7-8.9k, 4 -> 7.9k (8.6k with 24 hardware queues) trajectories/s
     depth = max(1, args.inflight)
@@ -177,14 +170,10 @@ def main():
     def issue(o_):
         # optimizeTraj:146-357: host-to-device copy of the raw init paths + the init kernel, then the persistent solve
         # kernels (optimizeTraj:359-497).  The maps stay resident (the reference builds its map before optimizeTraj).
-        if chain:
-            o_.reset()                   # chained batches run the init step inside the solve, from the resident paths
-        else:
-            o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids_of[id(o_)])
+        o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids_of[id(o_)])
         o_.optimize_async()
 
     gathers = []
-    deferred = []
     trace = os.environ.get("TOPAY_BENCH_TRACE") == "1"
     tr0 = time.perf_counter()
 
@@ -221,13 +210,10 @@ def main():
             tc = time.perf_counter()
             # the exchange of step i is started here and collected while step i+1's records are being prepared: the RCCL
             # kernel has to find a compute unit on a device whose SIMDs all hold resident solver waves of the next batch
-            if chain:
-                deferred.append(recs)    # gathered after the last step of the run, still inside the timed region
-            else:
-                gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
-                sent.append(recs)
-                while len(gathers) > 1:
-                    check_gather(tdist.gather_records_end(gathers.pop(0)))
+            gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
+            sent.append(recs)
+            while len(gathers) > 1:
+                check_gather(tdist.gather_records_end(gathers.pop(0)))
             if trace:
                 print(f"[trace] finish at {1e3 * (ta - tr0):.0f} ms: wait {1e3 * (tb_ - ta):.1f}, records {1e3 * (tc - tb_):.1f}, "
                       f"gather {1e3 * (time.perf_counter() - tc):.1f} ms", file=sys.stderr)
@@ -244,9 +230,6 @@ def main():
             issue(o_)
         for i in range(max(0, nsteps - depth_), nsteps):
             out_.append(finish(opts[i % depth_]))
-        while deferred:                  # chained run: the device is free again, one gather per step
-            sent.append(deferred[0])
-            gathers.append(tdist.gather_records_begin(deferred.pop(0), max_rows=S, device=dev))
         while gathers:                   # every step's records are on every rank before the step counts as done
             check_gather(tdist.gather_records_end(gathers.pop(0)))
         return out_
@@ -346,7 +329,7 @@ def main():
                          f"scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, tables map 20x20x1.6 m @0.1 m "
                          "regenerated per scenario, both stages + ALM to convergence"),
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
-            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU" + (", chained batches" if chain else ""),
+            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "max_pieces": int(n_pieces.max()),
             "pieces_over_32": int((n_pieces > 32).sum()),
             # candidates the device did not solve (more pieces than the build supports): none may hide in `value`

@@ -526,6 +526,27 @@ struct RobotModel {
     }
     return false;
   }
+  // The smallest slack |lhs - rhs| over every threshold comparison isWholeBodyCollision evaluates for this state (all
+  // of them, without the early exits): a state whose verdict could flip under last-bit rounding differences has a
+  // slack of the order of 1e-16; the parity tests only accept a differing verdict from such a tie.
+  double wholeBodyTieSlack(const GridMap& gm, const double* s) const {
+    double m = 1e300;
+    auto cmp = [&](double a, double b) { m = std::min(m, std::fabs(a - b)); };
+    for (int i = 0; i < 7; i++) { cmp(s[3 + i], qmax[i]); cmp(s[3 + i], qmin[i]); }
+    if (gm.isInMap2d(s[0], s[1])) cmp(gm.getDistance2d(s[0], s[1]), chassis_colli_radius);
+    double pts[12][4];
+    int n = getColliPts(s, pts);
+    for (int i = 0; i < n; i++) {
+      if (gm.isInMap3d(pts[i][0], pts[i][1], pts[i][2])) cmp(gm.getDistance3d(pts[i][0], pts[i][1], pts[i][2]), pts[i][3]);
+      double dx = pts[i][0] - s[0], dy = pts[i][1] - s[1];
+      if (i > 2) { cmp(pts[i][2], chassis_height + pts[i][3]); cmp(std::sqrt(dx * dx + dy * dy), chassis_colli_radius + pts[i][3]); }
+      for (int j = i + 2; j < n; j++) {
+        double d0 = pts[i][0] - pts[j][0], d1 = pts[i][1] - pts[j][1], d2 = pts[i][2] - pts[j][2];
+        cmp(std::sqrt(d0 * d0 + d1 * d1 + d2 * d2), pts[i][3] + pts[j][3]);
+      }
+    }
+    return m;
+  }
 };
 
 // ---- front-end stand-in ---------------------------------------------------------------
@@ -613,7 +634,8 @@ inline std::vector<std::array<double, 4>> getDensePath(const std::vector<std::ar
   for (size_t i = 1; i < raw.size(); i++) {
     double dx = raw[i][0] - raw[i - 1][0], dy = raw[i][1] - raw[i - 1][1];
     double len = std::sqrt(dx * dx + dy * dy);
-    double ux = dx / len, uy = dy / len;
+    // Eigen::normalized(): a zero-length vector stays zero (graph_search.cpp:128)
+    double ux = len > 0.0 ? dx / len : 0.0, uy = len > 0.0 ? dy / len : 0.0;
     int times = (int)std::max(std::ceil(len / step_size), 1.0);
     double step = len / times;
     for (int j = 1; j <= times; j++) dense.push_back({raw[i - 1][0] + (step * j) * ux, raw[i - 1][1] + (step * j) * uy});

@@ -49,6 +49,8 @@ def lib():
         L.wl_sample_arm.argtypes = [C.c_void_p, C.c_uint64, c_dp]
         L.wl_sample_scenario.argtypes = [C.c_void_p, C.c_uint64, c_dp, c_dp]
         L.wl_whole_body_collision.argtypes = [C.c_void_p, c_dp]
+        L.wl_whole_body_tie_slack.argtypes = [C.c_void_p, c_dp]
+        L.wl_whole_body_tie_slack.restype = C.c_double
         L.wl_init_paths.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, C.c_uint64, c_dp, C.c_int, c_ip]
         L.wl_tables_batch_create.restype = C.c_void_p
         L.wl_tables_batch_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -123,6 +125,11 @@ class World:
     def collision(self, state):
         st = np.ascontiguousarray(state, dtype=np.float64)
         return bool(lib().wl_whole_body_collision(self.h, _dp(st)))
+
+    def collision_tie_slack(self, state):
+        """Smallest |lhs - rhs| over all threshold comparisons of isWholeBodyCollision for this state."""
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        return float(lib().wl_whole_body_tie_slack(self.h, _dp(st)))
 
     def init_paths(self, start, goal, n_cand, seed, max_states=20000):
         start = np.ascontiguousarray(start, dtype=np.float64)

@@ -59,6 +59,11 @@ int wl_whole_body_collision(void* h, const double* state) {
   return w->robot.isWholeBodyCollision(w->gm, state) ? 1 : 0;
 }
 
+double wl_whole_body_tie_slack(void* h, const double* state) {
+  World* w = (World*)h;
+  return w->robot.wholeBodyTieSlack(w->gm, state);
+}
+
 // returns number of candidates produced; out_paths holds sum(lens) x 10 doubles (capacity max_states)
 int wl_init_paths(void* h, const double* start, const double* goal, int n_cand, uint64_t seed, double* out_paths,
                   int max_states, int* out_lens) {

@@ -193,8 +193,7 @@ topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len,
                                  const double* boundary_vel, const double* boundary_acc, const int* map_ids);
 
 /* Re-run the init kernel from the resident raw paths (restores x0 so the same batch can be
- * optimised again; used by bench.py so every timed step starts from HBM-resident inputs).  With batch chaining
- * (TOPAY_CHAIN=1) the init step runs inside the solve and this call does nothing. */
+ * optimised again without uploading the paths a second time). */
 topay_status topay_reset(topay_ctx* ctx);
 
 /* == optimizeTraj lines 359-497 for every batch member (stage-1 L-BFGS, stage-2 ALM loop). */
@@ -319,6 +318,13 @@ topay_status topay_get_x(topay_ctx* ctx, int i, int* n, double* x);
 topay_status topay_eval(topay_ctx* ctx, int stage, int i, const double* x, const double* alm_lambda,
                         const double* alm_rho, double* f, double* g, double* final_xy_error);
 
+/* The spline of a given decision vector as candidate i's result.  MomaTrajOpt keeps the MINCO state of its last cost
+ * evaluation and getTraj() returns it (moma_traj_opt.h:943-946; secondStageCostCallback, moma_traj_opt.cpp:885-955):
+ * one stage-2 evaluation at x with the ALM state (lambda, rho), after which topay_get_result(s), topay_playback,
+ * topay_mesh_traj, topay_get_polytraj_msg and the feasibility gate serve x's trajectory (replay / warm-start entry;
+ * the stored cost is the stage-2 cost at x, success is set). */
+topay_status topay_load_solution(topay_ctx* ctx, int i, const double* x, const double* alm_lambda, const double* alm_rho);
+
 /* Batched form of the hook over candidates [0, batch): x is batch x nmax (row stride nmax from
  * topay_get_nmax), g likewise; used by bench.py to time the cost/gradient kernel on its own. */
 topay_status topay_eval_batch(topay_ctx* ctx, int stage, int repeats, double* f /* batch */);
@@ -342,6 +348,11 @@ topay_status topay_get_trace(topay_ctx* ctx, int i, double* out);
 /* Test hook for the deterministic elementary functions of the solver (topay_amd/csrc/topay_math.h):
  * out[4i..] = sin(a_i), cos(a_i), atan2(a_i, b_i), sqrt(|a_i|)/(1+|b_i|). */
 topay_status topay_test_math(topay_ctx* ctx, int n, const double* a, const double* b, double* out4n);
+
+/* Scheduling diagnostics: how often topay_optimize_async gave up waiting (120 s) for the previously issued batch to
+ * become resident before issuing this context's batch (the dispatch gate only orders batches; results never depend on
+ * it).  Non-zero means the device was stalled by something else; topay_last_error() then holds the message. */
+topay_status topay_gate_timeouts(topay_ctx* ctx, int* n);
 
 /* Device time (HIP events on the context's stream) of the last topay_optimize / topay_eval_batch
  * solve kernel(s), in milliseconds, and the number of launches it covered. */

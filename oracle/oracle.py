@@ -263,7 +263,7 @@ def optimize_batch(m, path_len, paths, bvel=None, bacc=None, nthreads=1, alm_max
     return out
 
 
-def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1):
+def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1, gate=False):
     """Thread-pool batch solve where trajectory b runs against maps[map_id[b]] (cpu_baseline leg of bench.py)."""
     L = lib()
     M = len(maps)
@@ -284,8 +284,13 @@ def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1):
     npc = np.zeros(B, dtype=np.int32)
     stats = np.zeros(B * 8, dtype=np.int32)
     each = np.zeros(B)
+    dur = np.zeros(B) if gate else None
+    gt = np.zeros(B, dtype=np.int32) if gate else None
     L.orc_optimize_batch_maps.restype = C.c_double
     secs = L.orc_optimize_batch_maps(M, _dp(origin), _dp(res), _ip(dims), _dp(mn), _dp(mx), e2, e3, _ip(map_id), B,
                                      _ip(path_len), _dp(paths), nthreads, _ip(success), _dp(cost), _ip(npc), _ip(stats),
-                                     _dp(each))
-    return dict(success=success, cost=cost, n_pieces=npc, stats=stats.reshape(B, 8), seconds=secs, seconds_each=each)
+                                     _dp(each), _dp(dur), _ip(gt))
+    out = dict(success=success, cost=cost, n_pieces=npc, stats=stats.reshape(B, 8), seconds=secs, seconds_each=each)
+    if gate:   # total duration and printConstraintsSituations verdict of every returned trajectory
+        out.update(total_duration=dur, gate=gt)
+    return out

@@ -248,7 +248,8 @@ double orc_optimize_batch_maps(int n_maps, const double* origin /*[M][3]*/, cons
                                const int* dims /*[M][3]*/, const double* min_b, const double* max_b,
                                const double* const* esdf2d, const double* const* esdf3d, const int* map_id, int batch,
                                const int* path_len, const double* paths, int nthreads, int* success, double* cost,
-                               int* n_pieces, int* stats, double* seconds_each) {
+                               int* n_pieces, int* stats, double* seconds_each, double* total_duration /* may be null */,
+                               int* gate /* may be null: printConstraintsSituations of the returned trajectory */) {
   std::vector<size_t> offs(batch + 1, 0);
   for (int b = 0; b < batch; b++) offs[b + 1] = offs[b] + (size_t)path_len[b] * 10;
   std::vector<double> zeros(20, 0.0);
@@ -275,6 +276,19 @@ double orc_optimize_batch_maps(int n_maps, const double* origin /*[M][3]*/, cons
       int* s = stats + (size_t)b * 8;
       s[0] = st.stage1_ret; s[1] = st.stage1_iters; s[2] = st.stage1_evals; s[3] = st.stage2_last_ret;
       s[4] = st.stage2_iters; s[5] = st.stage2_evals; s[6] = st.alm_outer; s[7] = st.sum_bound;
+      if (total_duration || gate) {   // what the planner ranks and gates the candidate by (planner.cpp:878-880, 999-1010)
+        const int N = h.opt.piece_num;
+        std::vector<double> d(N), c((size_t)N * 54), k((size_t)(N + 1) * 2);
+        h.opt.getTraj(d.data(), c.data(), k.data());
+        double t = 0.0;
+        for (int i = 0; i < N; i++) t += d[i];
+        if (total_duration) total_duration[b] = t;
+        if (gate) {
+          double rep[38];
+          bool strict = false;
+          gate[b] = (std::isfinite(t) && t > 0.0 && t < 1.0e4 && h.opt.checkSituations(rep, &strict)) ? 1 : 0;
+        }
+      }
     }
   };
   std::vector<std::thread> th;

@@ -1,0 +1,165 @@
+"""The data-format rows on the HIP path against the ORACLE (not against the emulator build of the same sources):
+getTraj / getTrajs (moma_traj_opt.h:943-946), MomaTraj playback (26-137), PolyTraj.msg (src/planner/msg/PolyTraj.msg),
+MeshTraj (planner.cpp:2003-2056), the golden fixture's gate / playback entries, and the bench-scale statistics of
+device solves against oracle solves (planner.cpp:999-1016: per-scenario winner)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import set_map
+from oracle import oracle as orc
+from topay_amd import api
+from harness import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_at(m, path, x, alm):
+    """The oracle holding the spline of the device's returned decision vector (its own MINCO solve of x)."""
+    o = orc.Oracle(m)
+    o.set_init_traj(path)
+    o.set_alm(alm[:2], alm[2:])
+    o.eval(2, x)
+    return o
+
+
+def test_trajectory_outputs_on_gpu_match_oracle():
+    """One tables scenario x 8 candidates solved on the device.  Every output that leaves the device for a solved
+    candidate is compared with the oracle's restatement evaluated at the device's returned x: coefficients, durations
+    and knots (single and batched fetch), car_seq and getState, the PolyTraj message fields, the MeshTraj message."""
+    world, start, goal, lens, paths = wl.tables_scenario(3, 8)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    m = orc.MapView(world.origin, world.res, world.dims, world.min_b, world.max_b, world.esdf2d, world.esdf3d)
+    gpu = api.MomaTrajOptBatch(device=0)
+    set_map(gpu, world)
+    ok = gpu.optimizeTraj(lens, paths)
+    assert ok.sum() >= 4
+    alm = gpu.alm_state()
+    solved = [int(b) for b in np.nonzero(ok)[0]]
+    batch = gpu.getTrajs(solved)
+    checked = 0
+    for k, b in enumerate(solved):
+        o = _oracle_at(m, paths[offs[b]:offs[b + 1]], gpu.get_x(b), alm[b])
+        d, c, kn = o.get_traj()
+        tr = gpu.getTraj(b)
+        scale = np.abs(c).max()
+        # getTraj: same spline (both sides solve the banded system of the same x; observed ~1e-13 relative)
+        assert np.allclose(tr["durations"], d, rtol=1e-13, atol=0)
+        assert np.abs(tr["coeffs"] - c).max() <= 1e-10 * scale
+        assert np.abs(tr["knots_xy"] - kn).max() <= 1e-10
+        # getTrajs: the packed winners' fetch returns the same numbers as the per-candidate call, hence the oracle's
+        p0, p1 = batch["piece_off"][k], batch["piece_off"][k + 1]
+        assert p1 - p0 == len(d)
+        assert (batch["durations"][p0:p1] == tr["durations"]).all() and (batch["coeffs"][p0:p1] == tr["coeffs"]).all()
+        assert (batch["knots_xy"][p0 + k:p1 + k + 1] == tr["knots_xy"]).all()
+        assert np.abs(batch["coeffs"][p0:p1] - c).max() <= 1e-10 * scale
+        # MomaTraj playback: car_seq (0.1 s grid from 0.025 s Simpson panels) and getState, inside and outside [0, T]
+        T = d.sum()
+        times = np.concatenate([[0.0, T, T + 1.0, -0.5], np.linspace(0, T, 41)])
+        st, seq = gpu.playback(b, times)
+        seq_o = o.car_seq()
+        assert len(seq) == len(seq_o) and np.abs(seq - seq_o).max() <= 1e-10
+        for q, t in enumerate(times):
+            assert np.abs(st[q] - o.traj_state(float(t))).max() <= 1e-10, (b, t)
+        # PolyTraj.msg: float32 coefficient / duration arrays of the same spline, order 5, direction = sign of ds/dt mid-piece
+        order, cf32, du32, dirs = gpu.polytraj_msg(b)
+        assert order == 5 and cf32.dtype == np.float32 and du32.dtype == np.float32
+        assert np.abs(cf32.astype(np.float64) - c).max() <= 1.2e-7 * scale and np.abs(du32.astype(np.float64) - d).max() <= 1.2e-7 * d.max()
+        # (bit-equal to the float32 rounding of the oracle's doubles except where a double sits on a rounding boundary)
+        assert (cf32 == c.astype(np.float32)).mean() > 0.999 and (du32 == d.astype(np.float32)).all()
+        mid = np.array([np.polyval(np.arange(5, 0, -1) * c[p, 1, :5], 0.5 * d[p]) for p in range(len(d))])
+        assert (dirs == np.where(mid < 0, -1, 1)).all()
+        # MeshTraj message (1000 steps): poses of all parts, yaws, arc lengths
+        if checked < 3:
+            P, Y, A = o.mesh_traj(1000)
+            Pg, Yg, Ag = gpu.mesh_traj(b, 1000)
+            assert len(Yg) == len(Y) and np.abs(P - Pg).max() <= 1e-10 and np.abs(Y - Yg).max() <= 1e-10 and np.abs(A - Ag).max() <= 1e-10
+        checked += 1
+    # feasibility gate of the same batch: verdicts identical to the oracle's, extremes to 1e-9 relative
+    f, stq, rep = gpu.check_feasible(report=True)
+    for b in solved:
+        o = _oracle_at(m, paths[offs[b]:offs[b + 1]], gpu.get_x(b), alm[b])
+        fo, so, ro = o.check_feasible()
+        assert fo == f[b] and so == stq[b] and np.allclose(np.abs(ro), rep[b], rtol=1e-9, atol=1e-11)
+    world.close()
+
+
+def test_golden_gate_and_playback_on_gpu(cuboids_small):
+    """The fixture's fully solved trajectory (tests/golden: full_x and the gate report, car_seq, mid state stored with
+    it) loaded into the device through topay_load_solution: gate verdicts, the 38 extremes, car_seq and getState."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cuboids_seed42.npz"))
+    gpu = api.MomaTrajOptBatch(device=0)
+    set_map(gpu, cuboids_small["world"])
+    gpu.set_init_traj(gold["lens"], gold["paths"])
+    gpu.load_solution(0, gold["full_x"], [0.0, 0.0], [1e4, 1e4])
+    f, st, rep = gpu.check_feasible(report=True)
+    assert [int(f[0]), int(st[0])] == list(gold["full_gate"])
+    assert np.allclose(rep[0], np.abs(gold["full_gate_report"]), rtol=1e-9, atol=1e-11)
+    T = gold["full_dur"].sum()
+    states, seq = gpu.playback(0, np.array([0.37 * T]))
+    assert len(seq) == len(gold["full_car_seq"]) and np.abs(seq - gold["full_car_seq"]).max() <= 1e-10
+    assert np.abs(states[0] - gold["full_state_mid"]).max() <= 1e-10
+    tr = gpu.getTraj(0)
+    assert np.allclose(tr["durations"], gold["full_dur"], rtol=1e-12) and np.abs(tr["knots_xy"] - gold["full_knots"]).max() <= 1e-9
+    assert tr["success"] and np.isfinite(tr["cost"])
+
+
+def test_benchmark_slice_statistics_match_the_oracle():
+    """192 scenarios x 8 candidates of the headline batch (bench.py's seed-42 generator, one map per scenario): device
+    solves against oracle solves of the same 1536 candidates.  Converged values differ candidate by candidate (chaotic
+    iteration), so the assertions are the ones bench.py's numbers rest on: success fraction, cost
+    distribution decile by decile, stage-1 counters (not chaotic), and what the planner keeps of a scenario
+    (planner.cpp:999-1016): whether it is solved at all, and the duration of its winner."""
+    S, Cc = 192, 8
+    tb = wl.TablesBatch(S, Cc, base_seed=42, nthreads=8)
+    gpu = api.MomaTrajOptBatch(device=0)
+    worlds = [tb.world(s_) for s_ in tb.scenarios]
+    w0 = worlds[0]
+    gpu.build_esdf_batch(w0.origin, w0.res, w0.dims, w0.min_b, w0.max_b, np.stack([w.occ2d for w in worlds]), np.stack([w.occ3d for w in worlds]))
+    slot = {s_: k for k, s_ in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s_] for s_ in tb.scen], dtype=np.int32)
+    ok = gpu.optimizeTraj(tb.lens, tb.paths, map_ids=map_ids)
+    gate = gpu.check_feasible()
+    dur = gpu.total_durations()
+    st = gpu.stats()
+    cost = gpu.traj_cost.copy()
+    views = [orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d) for w in worlds]
+    r = orc.optimize_batch_maps(views, map_ids, tb.lens, tb.paths, nthreads=16, gate=True)
+    ro, rg, rd = r["success"] == 1, r["gate"] == 1, r["total_duration"]
+    assert (gpu.n_pieces() == r["n_pieces"]).all()
+    # stage 1 is short and not chaotic: identical return codes and counters for nearly every candidate
+    s1_same = (st[:, :3] == r["stats"][:, :3]).all(axis=1).mean()
+    # success and gate fractions
+    acc_dev, acc_ref = (ok & gate), (ro & rg)
+    print(f"slice: success dev {ok.mean():.4f} ref {ro.mean():.4f}; accepted dev {acc_dev.mean():.4f} ref {acc_ref.mean():.4f}; "
+          f"same success verdict {np.mean(ok == ro):.4f}; stage-1 counters equal {s1_same:.4f}")
+    assert s1_same > 0.97
+    assert abs(ok.mean() - ro.mean()) < 0.02 and abs(acc_dev.mean() - acc_ref.mean()) < 0.03
+    assert np.mean(ok == ro) > 0.93
+    # cost distribution of the converged candidates, decile by decile (1500 samples: the distribution is smooth)
+    both = ok & ro
+    dec = [float(np.percentile(cost[both], q) / np.percentile(r["cost"][both], q)) for q in range(10, 100, 10)]
+    same_min = np.mean(np.abs(cost[both] / r["cost"][both] - 1.0) < 0.05)
+    print(f"slice: deciles dev/ref {[round(v, 4) for v in dec]}; {same_min:.3f} of the candidates end within 5 % of the oracle's cost")
+    assert max(abs(v - 1.0) for v in dec) < 0.03
+    assert same_min > 0.75
+    # the planner's view: per scenario the shortest accepted candidate
+    def winners(acc, d):
+        out = {}
+        for b in np.nonzero(acc)[0]:
+            s_ = int(tb.scen[b])
+            if s_ not in out or d[b] < d[out[s_]]:
+                out[s_] = int(b)
+        return out
+    wd, wr = winners(acc_dev, dur), winners(acc_ref, rd)
+    solved_same = np.mean([(s_ in wd) == (s_ in wr) for s_ in tb.scenarios])
+    common = [s_ for s_ in tb.scenarios if s_ in wd and s_ in wr]
+    same_winner = np.mean([wd[s_] == wr[s_] for s_ in common])
+    dur_ratio = np.array([dur[wd[s_]] / rd[wr[s_]] for s_ in common])
+    print(f"slice: scenarios solved dev {len(wd)} ref {len(wr)} of {S} (same verdict {solved_same:.3f}); same winner {same_winner:.3f}; "
+          f"winner duration dev/ref median {np.median(dur_ratio):.4f}, within 5 %: {np.mean(np.abs(dur_ratio - 1) < 0.05):.3f}")
+    assert solved_same > 0.95 and abs(len(wd) - len(wr)) <= 0.03 * S
+    assert abs(np.median(dur_ratio) - 1.0) < 0.01 and np.mean(np.abs(dur_ratio - 1) < 0.05) > 0.8
+    assert same_winner > 0.5
+    tb.close()

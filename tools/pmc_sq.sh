@@ -1,5 +1,8 @@
 #!/bin/bash
 # SQ counter passes over one serial bench step (where do the wave cycles of the solve kernels go).  Run through gpurun.
+# the profiler's preloaded library initialises HIP before python starts: the library's own setenv / bench.py's setdefault
+# come too late, so the 24 hardware queues of the shipped configuration are asked for here
+export GPU_MAX_HW_QUEUES=24
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq_${1:-r02}
 mkdir -p $OUT

@@ -1,6 +1,9 @@
 #!/bin/bash
 # rocprofv3 passes over the ESDF-gather kernel alone (tools/k1_gather.py): kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in separate passes.  Run through gpurun; outputs under gpurun_out/k1_$1_{tables,hires}.
+# the profiler's preloaded library initialises HIP before python starts: the library's own setenv / bench.py's setdefault
+# come too late, so the 24 hardware queues of the shipped configuration are asked for here
+export GPU_MAX_HW_QUEUES=24
 R=${1:-r02}; KIND=${2:-tables}; REPS=${3:-20}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/k1_${R}_$KIND

@@ -2,6 +2,9 @@
 # Round profile on the GPU box (run through gpurun): kernel trace + stats of the bench command, then separate PMC passes
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass), then the counter calibration.  Outputs under gpurun_out/prof_$1.
 # usage: tools/profile_round.sh [round tag] [hires]   -- with `hires`: the same three passes on BASELINE configs[4] (4 GB field) only
+# the profiler's preloaded library initialises HIP before python starts: the library's own setenv / bench.py's setdefault
+# come too late, so the 24 hardware queues of the shipped configuration are asked for here
+export GPU_MAX_HW_QUEUES=24
 R=${1:-r02}
 WL=$2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -119,6 +119,8 @@ def load(path=None):
     L.topay_get_elapsed_us.argtypes = [C.c_void_p, c_dp, c_dp, c_ip]
     L.topay_get_x.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.topay_load_solution.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
+    L.topay_gate_timeouts.argtypes = [C.c_void_p, c_ip]
     L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
     L.topay_get_nmax.argtypes = [C.c_void_p, c_ip, c_ip]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
@@ -527,6 +529,18 @@ class MomaTrajOptBatch:
         rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
         _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
         return f.value, g, e
+
+    def load_solution(self, i, x, alm_lambda=None, alm_rho=None):
+        """Make the spline of the decision vector x candidate i's result (getTraj() after an evaluation at x)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lam = None if alm_lambda is None else np.ascontiguousarray(alm_lambda, dtype=np.float64)
+        rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
+        _chk(self.L, self.L.topay_load_solution(self.h, i, _dp(x), _dp(lam), _dp(rho)))
+
+    def gate_timeouts(self):
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_gate_timeouts(self.h, C.byref(n)))
+        return n.value
 
     def _mesh_params(self):
         m = MeshParams()

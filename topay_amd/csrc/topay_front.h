@@ -26,8 +26,10 @@ __device__ __forceinline__ int dense_path(const double* raw, int nraw, double st
   auto seg_setup = [&]() {
     const double dx = raw[2 * seg] - raw[2 * (seg - 1)], dy = raw[2 * seg + 1] - raw[2 * (seg - 1) + 1];
     const double len = sqrt(dx * dx + dy * dy);
-    ux = dx / len;
-    uy = dy / len;
+    // Eigen's normalized() returns the zero vector for a zero-length input (a repeated raw point): the samples of such a
+    // leg are the point itself
+    ux = len > 0.0 ? dx / len : 0.0;
+    uy = len > 0.0 ? dy / len : 0.0;
     const double t = ceil(len / step_size);
     times = (int)(t > 1.0 ? t : 1.0);
     step = len / times;

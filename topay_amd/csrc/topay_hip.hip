@@ -85,6 +85,8 @@ template <int RMAX>
 __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds,
                                           int init_stride_N, int repeats) {
   const int b = Bt.order[blockIdx.x];
+  const bool commit = (stage & 16) != 0;
+  stage &= 15;
   EvalCtx C;
   load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
@@ -108,23 +110,22 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
     Bt.xyerr[2 * b] = C.fxe0;
     Bt.xyerr[2 * b + 1] = C.fxe1;
   }
+  if (commit) {   // topay_load_solution: the spline of this x becomes the candidate's result, as after a solve that ended here
+    __syncthreads();
+    const int N = C.N, rows = C.rows;
+    double* coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
+    for (int t = C.lane; t < 9 * rows; t += 64) coef[t] = C.cL[t];
+    if (C.lane < N) Bt.T[(size_t)b * Bt.Nmax + C.lane] = C.Tp[C.lane];
+    double* kn = Bt.knots + (size_t)b * 2 * (Bt.Nmax + 1);
+    if (C.lane == 0) { kn[0] = C.sx; kn[1] = C.sy; }
+    for (int t = C.lane; t < 2 * N; t += 64) kn[2 + t] = C.pcs[2 * N + 2 + t];
+    if (C.lane == 0) { Bt.cost[b] = f; Bt.success[b] = 1; }
+  }
 }
 
-__device__ __noinline__ void init_candidate(const DevBatch& Bt, int b) {
-  init_one(g_P, Bt.in_paths + Bt.in_off[b] * 10, Bt.in_len[b], Bt.in_bvel + (size_t)b * 20, Bt.in_bacc + (size_t)b * 20,
-           Bt.in_scratch + (size_t)b * Bt.in_scratch_stride, Bt.in_maxN, Bt.N + b, Bt.s1_past + b, Bt.head + (size_t)b * 27,
-           Bt.tail + (size_t)b * 27, Bt.start_xy + 2 * b, Bt.goal_xy + 2 * b, Bt.init_xy + (size_t)b * 2 * Bt.in_maxN,
-           Bt.x0 + (size_t)b * Bt.in_stride_n);
-}
-
-template <int RMAX, bool CHAIN>
+template <int RMAX>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N, int b) {
   const unsigned long long t_begin = wall_clock64();
-  if (CHAIN && Bt.in_paths) {  // optimizeTraj:146-357 for this candidate (one lane; the result is what the init kernel writes)
-    if (threadIdx.x == 0) init_candidate(Bt, b);
-    __threadfence();
-    __syncthreads();
-  }
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
   // is resident, see topay_optimize_async
   if (threadIdx.x == 0 && Bt.started && Bt.N[b] <= Bt.gate_maxN) {
@@ -187,45 +188,27 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
     Bt.hw_id[b] = 0;
 #endif
   }
-  if (CHAIN && Bt.chain) {
-    // completion signal of a chained batch: results first (release at system scope), then the count
-#ifndef TOPAY_CPU_EMU
-    __threadfence_system();
-    if (threadIdx.x == 0)
-      __hip_atomic_fetch_add(&Bt.chain->finished[Bt.chain_gen & (TOPAY_CHAIN_SLOTS - 1)], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    if (threadIdx.x == 0) Bt.chain->finished[Bt.chain_gen & (TOPAY_CHAIN_SLOTS - 1)] += 1;
-#endif
-  }
 }
 
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX, bool SYSTEM_SCOPE>
+template <int RMAX>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int init_stride_N, int my_class) {
-  const bool queued = SYSTEM_SCOPE || B.queue_next != nullptr;
+  const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
   for (int cls = my_class; cls >= lowest; cls--) {
     const int count = queued ? B.queue_count[cls] : 1, off = queued ? B.queue_off[cls] : (int)blockIdx.x;
     for (int once = 0;; once++) {
       int pos = 0;
       if (queued) {
-        if (threadIdx.x == 0) {
-#ifndef TOPAY_CPU_EMU
-          // chained batches keep their counters in the pinned control block: system scope
-          pos = SYSTEM_SCOPE ? __hip_atomic_fetch_add(B.queue_next + cls, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                             : atomicAdd(B.queue_next + cls, 1);
-#else
-          pos = atomicAdd(B.queue_next + cls, 1);
-#endif
-        }
+        if (threadIdx.x == 0) pos = atomicAdd(B.queue_next + cls, 1);
         pos = __shfl(pos, 0);
       } else {
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX, SYSTEM_SCOPE>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
+      solve_one<RMAX>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -237,92 +220,26 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // of the slots stay empty when it has to place 8000 workgroups of unequal length); a resident wave that fetches its
 // next candidate itself leaves no slot idle and starts candidates strictly in queue order.  Which wave solves which
 // candidate is timing-dependent, the result of a candidate is not (nothing is shared between candidates).
-template <int RMAX, bool CHAIN>
+template <int RMAX>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N) {
-  const int my_class = Bt.queue_class;
-  if (!CHAIN) {   // plain persistent launch: the batch is the kernel argument (scalar loads, no copy)
-    drain_queues<RMAX, false>(Bt, maps, Nmax_lds, init_stride_N, my_class);
-    return;
-  }
-  DevBatch cur = Bt;
-  const DevMap* cmaps = maps;
-  for (;;) {
-    drain_queues<RMAX, true>(cur, cmaps, Nmax_lds, init_stride_N, my_class);
-    // out of work in this batch: go on with the next one if the host has published it (ChainCtl), else end the chain
-    ChainCtl* ch = cur.chain;
-    if (!ch) break;
-    const int gen = cur.chain_gen;
-    int st = 0;
-    if (threadIdx.x == 0) {
-#ifndef TOPAY_CPU_EMU
-      st = __hip_atomic_load(&ch->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (st == gen) {
-        int expected = gen;
-        if (__hip_atomic_compare_exchange_strong(&ch->state, &expected, -2 - gen, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM)) st = -2 - gen;
-        else st = expected;   // the host has just published gen + 1 (or another workgroup ended the chain)
-      }
-#else
-      st = ch->state;
-      if (st == gen) { ch->state = -2 - gen; st = -2 - gen; }
-#endif
-    }
-    st = __shfl(st, 0);
-    // newest published generation, whether the chain is still open (st >= 0) or ended (st = -2 - newest): a workgroup
-    // that lags behind still has to serve every generation that was published before the chain ended
-    const int newest = st >= 0 ? st : -2 - st;
-    // this workgroup has left generation gen: its slot of the control block may be reused once all have (ChainCtl)
-    if (threadIdx.x == 0) {
-#ifndef TOPAY_CPU_EMU
-      __hip_atomic_fetch_add(&ch->departed[gen & (TOPAY_CHAIN_SLOTS - 1)], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-      ch->departed[gen & (TOPAY_CHAIN_SLOTS - 1)] += 1;
-#endif
-    }
-    if (newest <= gen) break;
-#ifndef TOPAY_CPU_EMU
-    __threadfence_system();
-#endif
-    const ChainDesc* nd = &ch->desc[(gen + 1) & (TOPAY_CHAIN_SLOTS - 1)];
-    cur = nd->d;
-    cmaps = nd->maps;
-    __syncthreads();
-  }
+  drain_queues<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<1, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<1, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<1>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<2, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<2, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<2>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<3, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-// the same solve for chained batches (ChainCtl): in-solve init, completion counter, continuation with the next batch
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<3, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<3>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 // classes 4 and 5: four (N <= 42) and six (N <= 64) system rows per lane
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<4, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<4, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<4>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve6(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<6, false>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_chain6(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<6, true>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
+  solve_body<6>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
 }
 __global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
   eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
@@ -505,27 +422,6 @@ static std::mutex g_issue_mutex;
 static std::mutex g_registry_mutex;
 static std::vector<topay_ctx*> g_contexts;
 
-// Host side of batch chaining (ChainCtl, topay_types.h): per device two control blocks / stream sets used alternately by
-// successive chains, so that a new chain can start while the workgroups of a chain that has just ended finish their
-// last candidates.
-struct ChainHost {
-  bool inited = false;
-  ChainCtl* h[2] = {nullptr, nullptr};   // pinned host memory
-  ChainCtl* d[2] = {nullptr, nullptr};   // the same blocks as the device sees them
-  hipStream_t st[2][TOPAY_NBUCKET] = {{nullptr}};
-  hipEvent_t start_ev[2] = {nullptr, nullptr};
-  int set = 0;
-  bool alive = false;
-  int gen = 0;                           // latest generation published (or launched) on the current set
-  int nm[TOPAY_NBUCKET] = {0};           // LDS sizing (max N) of the running kernels per class
-  bool has[TOPAY_NBUCKET] = {false};
-  DevParams dp;
-  int nwg = 0;                           // workgroups of the running chain (all classes)
-  int n_of_slot[TOPAY_CHAIN_SLOTS] = {0};
-  topay_ctx* owner[TOPAY_CHAIN_SLOTS] = {nullptr};   // context whose batch used the slot last, and that batch's generation
-  int owner_gen[TOPAY_CHAIN_SLOTS] = {0};
-};
-static ChainHost g_chain[16];
 static topay_ctx* g_last_issued = nullptr;
 
 struct topay_ctx {
@@ -558,12 +454,9 @@ struct topay_ctx {
   int n_launched = 0;        // candidates the pending solve launched
   int n_gate = 0;            // ... of which the dispatch gate waits for (the classes of up to 32 pieces)
   bool gate = true;
+  int gate_timeouts = 0;     // times the dispatch gate gave up waiting (topay_gate_timeouts)
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
-  bool chain_enabled = false;  // TOPAY_CHAIN: resident workgroups go on with the next published batch instead of exiting
-  bool chained_mode = false;   // the pending solve signals completion through the chain's counter, not through the stream
-  bool done_observed = false;  // ... and somebody has already seen that counter reach n_launched
-  int chain_set = 0, chain_gen = 0;
   int simd_slots = 1024;
   DevBuf qnext;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
@@ -762,7 +655,6 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     HIPCHK(hipEventCreate(&c->bevent[k]));
   }
   {
-    { const char* ce = getenv("TOPAY_CHAIN"); c->chain_enabled = ce && ce[0] == '1'; }
     { const char* se = getenv("TOPAY_STEAL"); c->steal = !(se && se[0] == '0'); }
     const char* pe = getenv("TOPAY_PERSISTENT");
     c->persistent = !(pe && pe[0] == '0');
@@ -771,8 +663,8 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     c->simd_slots = 4 * prop.multiProcessorCount;   // one wave per SIMD (TOPAY_WAVES_PER_EU = 1), four SIMDs per CU
     // A few slots are left to everything that is not a solve: the init kernel, the feasibility gate and the result
     // gather of the OTHER batches in flight, the runtime's copy kernels, a collective.  Resident solver waves own their
-    // SIMD's whole register file, so on a device they fill completely such a kernel waits until workgroups exit --
-    // with chained batches, for ever.  TOPAY_RESERVE_SLOTS=<n> keeps n slots free (default 0: use every slot).
+    // SIMD's whole register file, so on a device they fill completely such a kernel waits until workgroups exit.
+    // TOPAY_RESERVE_SLOTS=<n> keeps n slots free (default 0: use every slot).
     {
       const char* rs = getenv("TOPAY_RESERVE_SLOTS");
       const int reserve = rs ? atoi(rs) : 0;   // (measured: no gain from a standing reserve with two batches in flight)
@@ -799,13 +691,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
 
 void topay_destroy(topay_ctx* c) {
   if (!c) return;
-  if (c->pending) (void)topay_synchronize(c);   // a chained batch may still be read by resident workgroups
-  {
-    std::lock_guard<std::mutex> lk(g_issue_mutex);
-    ChainHost& ch = g_chain[c->device % 16];
-    for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++)
-      if (ch.owner[q] == c) ch.owner[q] = nullptr;
-  }
+  if (c->pending) (void)topay_synchronize(c);
   {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
     g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
@@ -889,13 +775,7 @@ static topay_status push_params(topay_ctx* c) {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
     for (topay_ctx* q : g_contexts)
       if (q != c && q->pending && q->device == c->device && memcmp(&q->dp, &c->dp, sizeof(DevParams)) != 0) {
-        if (q->chained_mode) {   // its kernels are not on its stream: wait for the batch's completion counter
-          const auto t0 = std::chrono::steady_clock::now();
-          while (!batch_done(q) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(600))
-            std::this_thread::sleep_for(std::chrono::microseconds(100));
-        } else {
-          HIPCHK(hipStreamSynchronize(q->stream));
-        }
+        HIPCHK(hipStreamSynchronize(q->stream));
       }
   }
   HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_P), &c->dp, sizeof(DevParams), 0, hipMemcpyHostToDevice, c->stream));
@@ -1279,7 +1159,6 @@ topay_status topay_reset(topay_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   c->solved = false;
-  if (c->chain_enabled && c->persistent) return TOPAY_OK;   // chained batches initialise inside the solve (DevBatch::in_paths)
   return run_init(c);
 }
 
@@ -1321,7 +1200,6 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
 typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
 typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
 static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve2, k_solve3, k_solve4, k_solve6};
-static const solve_kernel_t kChainKernels[TOPAY_NBUCKET] = {k_chain1, k_chain2, k_chain2, k_chain3, k_chain4, k_chain6};
 static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval2, k_eval3, k_eval4, k_eval6};
 
 // Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most its class can ask
@@ -1335,7 +1213,6 @@ static hipError_t set_kernel_attributes(int device) {
     for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
       const int lds = (int)solve_lds_bytes(kBucketMaxN[k]);
       e = hipFuncSetAttribute((const void*)kSolveKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kChainKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kEvalKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     g_attr_err[device % 16] = e;
@@ -1403,209 +1280,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
 }
 
 
-// ---- batch chaining (TOPAY_CHAIN=1) ---------------------------------------------------------------------------
-static bool batch_done(topay_ctx* p) {
-  if (!p->pending) return true;
-  if (p->chained_mode) {
-    if (p->done_observed) return true;
-    ChainHost& ch = g_chain[p->device % 16];
-    volatile int* f = &ch.h[p->chain_set]->finished[p->chain_gen & (TOPAY_CHAIN_SLOTS - 1)];
-    return *f >= p->n_launched;
-  }
-  return hipStreamQuery(p->stream) == hipSuccess;
-}
-
-static topay_status chain_init(ChainHost& ch) {
-  if (ch.inited) return TOPAY_OK;
-  for (int s_ = 0; s_ < 2; s_++) {
-    void* hp = nullptr;
-    HIPCHK(hipHostMalloc(&hp, sizeof(ChainCtl), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(hp, 0, sizeof(ChainCtl));
-    ch.h[s_] = (ChainCtl*)hp;
-    ch.h[s_]->state = -1;
-    void* dp = nullptr;
-    HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
-    ch.d[s_] = (ChainCtl*)dp;
-    for (int k = 0; k < TOPAY_NBUCKET; k++) HIPCHK(hipStreamCreateWithFlags(&ch.st[s_][k], hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&ch.start_ev[s_]));
-  }
-  ch.inited = true;
-  return TOPAY_OK;
-}
-
-static int host_load(int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-static bool host_cas(int* p, int expected, int desired) {
-  return __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
-}
-
-// Issues the solve of context c either by publishing its batch to the running chain (no launch: the resident
-// workgroups pick it up when they run out of work) or by launching a new chain.  Called with g_issue_mutex held.
-static topay_status issue_chained(topay_ctx* c) {
-  ChainHost& ch = g_chain[c->device % 16];
-  topay_status cs = chain_init(ch);
-  if (cs != TOPAY_OK) return cs;
-  // Batch-side preparation without a single device operation (a device occupied by resident workgroups runs nothing
-  // else, not even a small copy kernel): the queue counters live in the pinned control block, the parameter block is
-  // only rewritten when it does not hold this batch's parameters (which ends a running chain anyway), candidates that are never launched keep the
-  // success = 0 / cost = NaN that topay_set_init_traj wrote, and the init step runs inside the solve.
-  if (!(g_pushed_valid[c->device % 16] && memcmp(&g_pushed_dp[c->device % 16], &c->dp, sizeof(DevParams)) == 0)) {
-    topay_status ps = push_params(c);   // (what the constant block holds is not what this batch needs)
-    if (ps != TOPAY_OK) return ps;
-  }
-  DevBatch d = c->db;
-  d.in_paths = c->paths.as<double>();
-  d.in_off = c->path_off.as<long long>();
-  d.in_len = c->path_len.as<int>();
-  d.in_bvel = c->bvel.as<double>();
-  d.in_bacc = c->bacc.as<double>();
-  d.in_scratch = c->scratch.as<double>();
-  d.in_scratch_stride = (3 * c->Pmax + 1 + TOPAY_MAX_N) * ND;
-  d.in_maxN = TOPAY_MAX_N;
-  d.in_stride_n = 10 * TOPAY_MAX_N - 8;
-  int nm[TOPAY_NBUCKET] = {0}, nl = 0, o2 = 0;
-  for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {
-    d.queue_off[kk] = o2;
-    d.queue_count[kk] = (int)c->cls[kk].size();
-    o2 += d.queue_count[kk];
-    nl += d.queue_count[kk];
-    for (int b : c->cls[kk]) nm[kk] = std::max(nm[kk], c->hN[b]);
-  }
-  {
-    void* dp = nullptr;
-    HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
-    d.started = (int*)dp;
-  }
-  c->h_started[0] = 0;
-  c->n_launched = nl;
-  c->n_gate = nl;
-  d.gate_maxN = TOPAY_MAX_N;
-  c->done_observed = false;
-
-  bool chained = false;
-  if (ch.alive) {
-    bool ok = memcmp(&ch.dp, &c->dp, sizeof(DevParams)) == 0;
-    for (int k = 0; k < TOPAY_NBUCKET && ok; k++)
-      if (d.queue_count[k] > 0 && !(ch.has[k] && nm[k] <= ch.nm[k])) ok = false;
-    ChainCtl* h = ch.h[ch.set];
-    const int g = ch.gen;
-    if (ok && host_load(&h->state) == g) {
-      // the slot of generation g + 1 was last used by generation g + 1 - SLOTS: every workgroup of the chain has to
-      // have left that generation (which also means its batch is complete)
-      const int slot = (g + 1) & (TOPAY_CHAIN_SLOTS - 1);
-      const auto t0 = std::chrono::steady_clock::now();
-      auto owner_busy = [&]() {
-        topay_ctx* o = ch.owner[slot];
-        return o && o->pending && o->chained_mode && o->chain_set == ch.set && o->chain_gen == ch.owner_gen[slot] && !o->done_observed;
-      };
-      const bool slot_used = g + 1 >= TOPAY_CHAIN_SLOTS;   // generation g + 1 - SLOTS exists in this chain
-      bool timed_out = false;
-      while (slot_used && host_load(&h->departed[slot]) < ch.nwg && host_load(&h->state) >= 0) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { timed_out = true; break; }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-      }
-      if (timed_out) {
-        // never publish into a slot that may still be in use: report, and let the caller decide (the chain stays as it is)
-        set_err("chained solve: workgroups did not leave an old generation within 300 s");
-        return TOPAY_ERR_NO_DEVICE;
-      }
-      if (host_load(&h->state) == g) {
-        if (owner_busy() && ch.owner[slot] != c) ch.owner[slot]->done_observed = true;   // complete: seen just above
-        h->finished[slot] = 0;
-        h->departed[slot] = 0;
-        for (int q = 0; q < 8; q++) h->qnext[slot][q] = 0;
-        d.queue_next = &ch.d[ch.set]->qnext[slot][0];
-        ch.n_of_slot[slot] = nl;
-        ch.owner[slot] = c;
-        ch.owner_gen[slot] = g + 1;
-        d.chain = ch.d[ch.set];
-        d.chain_gen = g + 1;
-        d.order = c->db.order;
-        h->desc[slot].d = d;
-        h->desc[slot].maps = (const DevMap*)c->dmaps.p;
-        __atomic_thread_fence(__ATOMIC_RELEASE);
-        if (host_cas(&h->state, g, g + 1)) {
-          chained = true;
-          ch.gen = g + 1;
-          c->chain_set = ch.set;
-          c->chain_gen = g + 1;
-        } else {
-          ch.owner[slot] = nullptr;   // a workgroup ended the chain first: nobody will read the slot
-        }
-      }
-    }
-    if (!chained) ch.alive = false;
-  }
-  if (!chained) {
-    // a new chain on the other set; oldest-first hand-over from whatever is still running (dispatch gate)
-    topay_ctx* p = g_last_issued;
-    if (c->gate && p && p != c && p->pending && p->device == c->device && p->h_started) {
-      volatile int* cnt = p->h_started;
-      const auto t0 = std::chrono::steady_clock::now();
-      while (*cnt < p->n_gate) {
-        if (batch_done(p)) break;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
-        std::this_thread::sleep_for(std::chrono::microseconds(100));
-      }
-    }
-    const int s2 = ch.set ^ 1;
-    for (int k = 0; k < TOPAY_NBUCKET; k++) HIPCHK(hipStreamSynchronize(ch.st[s2][k]));  // the chain before the previous one: long over
-    ChainCtl* h = ch.h[s2];
-    {
-      // the kernels that last used this set have ended (synchronised above): whatever batch of theirs a context has
-      // not yet waited for is complete; its counter is about to be reused
-      std::lock_guard<std::mutex> lk(g_registry_mutex);
-      for (topay_ctx* q : g_contexts)
-        if (q != c && q->pending && q->chained_mode && q->device == c->device && q->chain_set == s2) q->done_observed = true;
-    }
-    for (int q = 0; q < TOPAY_CHAIN_SLOTS; q++) {
-      h->finished[q] = 0;
-      h->departed[q] = 0;
-      for (int r = 0; r < 8; r++) h->qnext[q][r] = 0;
-      ch.n_of_slot[q] = 0;
-      ch.owner[q] = nullptr;
-    }
-    d.queue_next = &ch.d[s2]->qnext[0][0];
-    __atomic_store_n(&h->state, 0, __ATOMIC_RELEASE);
-    ch.n_of_slot[0] = nl;
-    ch.owner[0] = c;
-    ch.owner_gen[0] = 0;
-    d.chain = ch.d[s2];
-    d.chain_gen = 0;
-    d.order = c->db.order;
-    int share[topay_ctx::NBUCKET] = {0};
-    compute_shares(c, c->simd_slots, share);
-    HIPCHK(set_kernel_attributes(c->device));
-    HIPCHK(hipEventRecord(ch.start_ev[s2], c->stream));
-    int launches = 0;
-    for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
-      ch.has[k] = d.queue_count[k] > 0;
-      ch.nm[k] = nm[k];
-      if (!ch.has[k]) continue;
-      d.queue_class = k;
-      const size_t lds = solve_lds_bytes(nm[k]);
-      hipStream_t st = ch.st[s2][k];
-      HIPCHK(hipStreamWaitEvent(st, ch.start_ev[s2], 0));
-      hipLaunchKernelGGL(kChainKernels[k], dim3(share[k]), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, nm[k]);
-      HIPCHK(hipGetLastError());
-      launches++;
-    }
-    c->last_launches = launches;
-    ch.nwg = 0;
-    for (int k = 0; k < topay_ctx::NBUCKET; k++)
-      if (ch.has[k]) ch.nwg += share[k];
-    ch.set = s2;
-    ch.alive = true;
-    ch.gen = 0;
-    ch.dp = c->dp;
-    c->chain_set = s2;
-    c->chain_gen = 0;
-  }
-  c->done_observed = false;
-  c->chained_mode = true;
-  c->pending = true;
-  g_last_issued = c;
-  return TOPAY_OK;
-}
+static bool batch_done(topay_ctx* p) { return !p->pending || hipStreamQuery(p->stream) == hipSuccess; }
 
 extern "C" {
 
@@ -1616,11 +1291,6 @@ topay_status topay_optimize_async(topay_ctx* c) {
     topay_status s0 = topay_synchronize(c);
     if (s0 != TOPAY_OK) return s0;
   }
-  if (c->chain_enabled && c->persistent) {
-    std::lock_guard<std::mutex> lk(g_issue_mutex);
-    return issue_chained(c);
-  }
-  c->chained_mode = false;
   {
     // Dispatch gate.  Batches of different contexts run on different streams; issued at the same time their waves
     // would be dispatched alternately and both would end in the same long tail.  Holding the new batch back until
@@ -1634,7 +1304,12 @@ topay_status topay_optimize_async(topay_ctx* c) {
       const auto t0 = std::chrono::steady_clock::now();
       while (*cnt < p->n_gate) {
         if (batch_done(p)) break;  // finished (or never launched anything)
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+          // scheduling only: the batch is issued anyway, but the caller can see that the hand-over did not happen
+          c->gate_timeouts++;
+          set_err("dispatch gate: the previous batch did not become resident within 120 s; issuing anyway");
+          break;
+        }
         std::this_thread::sleep_for(std::chrono::microseconds(100));
       }
     }
@@ -1669,29 +1344,6 @@ topay_status topay_optimize_async(topay_ctx* c) {
 topay_status topay_synchronize(topay_ctx* c) {
   if (!c) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
-  if (c->pending && c->chained_mode) {
-    // the kernels outlive the batch: completion is the chain's counter of finished candidates
-    ChainHost& ch = g_chain[c->device % 16];
-    int* f = &ch.h[c->chain_set]->finished[c->chain_gen & (TOPAY_CHAIN_SLOTS - 1)];
-    const auto t0 = std::chrono::steady_clock::now();
-    while (!c->done_observed && host_load(f) < c->n_launched) {
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) { set_err("chained solve did not complete"); return TOPAY_ERR_NO_DEVICE; }
-      std::this_thread::sleep_for(std::chrono::microseconds(50));
-    }
-    c->done_observed = true;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    // device time of the batch: first start to last end on the device's constant clock
-    std::vector<double> su(c->B), us(c->B);
-    HIPCHK(memcpy_sync(c, su.data(), c->startus.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
-    HIPCHK(memcpy_sync(c, us.data(), c->elapsed.p, (size_t)c->B * 8, hipMemcpyDeviceToHost));
-    double t_lo = 1e300, t_hi = 0.0;
-    for (int b = 0; b < c->B; b++)
-      if (c->hN[b] > 0) { t_lo = std::min(t_lo, su[b]); t_hi = std::max(t_hi, su[b] + us[b]); }
-    c->last_ms = t_hi > t_lo ? (t_hi - t_lo) * 1e-3 : 0.0;
-    c->solved = true;
-    c->pending = false;
-    return TOPAY_OK;
-  }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->pending) {
     float ms = 0.f;
@@ -1987,6 +1639,7 @@ topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, i
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
   const int N = c->hN[i], rows = 6 * N;
   if (N == 0) {  // not representable (more than TOPAY_MAX_N pieces): failed candidate, nothing else to report
     if (success) *success = 0;
@@ -2017,6 +1670,8 @@ topay_status topay_get_results(topay_ctx* c, int n, const int* idx, int cap_piec
   if (n < 0 || (n > 0 && (!idx || !piece_off))) return TOPAY_ERR_INVALID_ARG;
   if (n == 0) return TOPAY_OK;
   HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  if (!c->solved) { set_err("topay_get_results: the batch has not been optimised"); return TOPAY_ERR_NO_TRAJ; }
   std::vector<int> off((size_t)n + 1, 0);
   for (int k = 0; k < n; k++) {
     if (idx[k] < 0 || idx[k] >= c->B) return TOPAY_ERR_INVALID_ARG;
@@ -2037,6 +1692,8 @@ topay_status topay_get_results(topay_ctx* c, int n, const int* idx, int cap_piec
   double* d_kn = d_coef + (size_t)np * 54;
   HIPCHK(hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  // a selected candidate that was never launched (zero pieces) still owns one knot pair of the packed output: zeros
+  HIPCHK(hipMemsetAsync(d_kn, 0, (size_t)2 * (np + n) * 8, c->stream));
   hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(64), 0, c->stream, c->db, n, (const int*)d_idx, (const int*)d_off, d_dur,
                      d_coef, d_kn);
   HIPCHK(hipGetLastError());
@@ -2089,8 +1746,8 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
   return TOPAY_OK;
 }
 
-topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
-                        double* f, double* g, double* final_xy_error) {
+static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
+                             double* f, double* g, double* final_xy_error, bool commit) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B || (stage != 1 && stage != 2) || !x) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -2111,7 +1768,7 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   const size_t lds = solve_lds_bytes(N);
   if ((s = push_params(c)) != TOPAY_OK) return s;
   HIPCHK(set_kernel_attributes(c->device));
-  hipLaunchKernelGGL(kEvalKernels[bucket_of(N)], dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage, 1, N);
+  hipLaunchKernelGGL(kEvalKernels[bucket_of(N)], dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   tmp.release();
@@ -2119,6 +1776,23 @@ topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const d
   if (g) HIPCHK(memcpy_sync(c, g, c->work.as<double>() + (size_t)i * 4 * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
   if (final_xy_error) HIPCHK(memcpy_sync(c, final_xy_error, c->xyerr.as<double>() + 2 * i, 16, hipMemcpyDeviceToHost));
   return TOPAY_OK;
+}
+}  // extern "C"  (eval_one is internal)
+
+extern "C" {
+topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
+                        double* f, double* g, double* final_xy_error) {
+  return eval_one(c, stage, i, x, alm_lambda, alm_rho, f, g, final_xy_error, false);
+}
+
+// The spline of a given decision vector as candidate i's result (MomaTrajOpt keeps the MINCO state of its last cost
+// evaluation, moma_traj_opt.h:943-946: getTraj() after an evaluation at x returns exactly this): one stage-2
+// evaluation at x with the given ALM state, after which getTraj / playback / gate / message entry points serve x's
+// trajectory.  Replay and warm-start entry; the cost stored is the stage-2 cost at x.
+topay_status topay_load_solution(topay_ctx* c, int i, const double* x, const double* alm_lambda, const double* alm_rho) {
+  topay_status s = eval_one(c, 2, i, x, alm_lambda, alm_rho, nullptr, nullptr, nullptr, true);
+  if (s == TOPAY_OK) c->solved = true;
+  return s;
 }
 
 // Batched hook: evaluate every candidate `repeats` times at its packed initial guess x0 (ALM state = initial).
@@ -2229,6 +1903,12 @@ topay_status topay_test_math(topay_ctx* c, int n, const double* a, const double*
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(memcpy_sync(c, out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   da.release(); dbb.release(); dout.release();
+  return TOPAY_OK;
+}
+
+topay_status topay_gate_timeouts(topay_ctx* c, int* n) {
+  if (!c || !n) return TOPAY_ERR_INVALID_ARG;
+  *n = c->gate_timeouts;
   return TOPAY_OK;
 }
 

@@ -79,8 +79,6 @@ struct DevParams {
   double relT[3];
 };
 
-struct ChainCtl;
-
 // Per-batch device arrays (structure of arrays; strides Nmax / nmax fixed per batch).
 struct DevBatch {
   int B, Nmax, nmax, hist_m;
@@ -121,20 +119,6 @@ struct DevBatch {
   int* queue_next;
   int queue_count[TOPAY_NBUCKET], queue_off[TOPAY_NBUCKET], queue_class;
   int queue_lowest;   // 0: drain the smaller classes' queues too; = queue_class: own queue only (TOPAY_STEAL=0, profiling)
-  // Chained batches initialise a candidate inside the solve (optimizeTraj:146-357 by the workgroup that is about to solve
-  // it) instead of by a separate kernel: nothing but resident workgroups can run on a device they occupy.  Null in_paths:
-  // the init kernel has done it.
-  const double* in_paths;
-  const long long* in_off;
-  const int* in_len;
-  const double* in_bvel;
-  const double* in_bacc;
-  double* in_scratch;
-  int in_scratch_stride, in_maxN, in_stride_n;
-  // Batch chaining (persistent launches): when the queues of this batch are empty a workgroup does not exit but goes on
-  // with the batch the host has published in `chain` meanwhile (generation chain_gen + 1), see ChainCtl.  Null: exit.
-  ChainCtl* chain;
-  int chain_gen;
   int* started;       // one counter in pinned host memory: candidates of this launch that have begun (dispatch gate; may be null)
   int gate_maxN;      // ... counting only candidates with at most this many pieces (the common classes, see topay_optimize_async)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
@@ -142,32 +126,4 @@ struct DevBatch {
   const int* order;   // [B] block -> trajectory map
   double* trace;      // optional [B][trace_cap] f of every evaluation (debug / parity tooling), may be null
   int trace_cap;
-};
-
-// Control block of a chain of batches served by one set of resident workgroups (pinned host memory, read and written by
-// host and device with system-scope atomics).
-//   state = g >= 0 : the newest batch published to the chain is generation g (its descriptor is in desc[g & 3]; the
-//                    first batch of a chain, generation 0, travels in the kernel arguments).  A workgroup that runs out
-//                    of work in generation b goes on with b + 1 if state > b.
-//   state = -2 - g : a workgroup found nothing newer than g when it ran out of work (it moved state from g to -2 - g): the
-//                    chain is over; every workgroup still serves the generations up to g, then exits; the host launches
-//                    afresh.  (-1: no chain has used the block yet.)
-// finished[g & 3] counts the candidates of generation g whose results are in memory (release at system scope before the
-// increment): the host's completion signal, since the kernels outlive the batch.  departed[g & 3] counts the workgroups
-// that have LEFT generation g (moved on to g + 1, or exited): from then on they touch neither its descriptor nor its
-// queue counters nor its completion counter.  A slot is reused for generation g + 4 only after every workgroup of the
-// chain has left generation g -- candidates finishing is not enough: a workgroup that has just finished its last
-// candidate of g still issues the fetch-adds that tell it the queues are empty, and reads the next descriptor.
-#define TOPAY_CHAIN_SLOTS 4
-struct ChainDesc {
-  DevBatch d;
-  const DevMap* maps;
-};
-struct ChainCtl {
-  int state;
-  int pad[3];
-  int finished[TOPAY_CHAIN_SLOTS];
-  int departed[TOPAY_CHAIN_SLOTS];
-  int qnext[TOPAY_CHAIN_SLOTS][8];   // work-queue counters of the batch in slot g & 3 (reset by the host without touching the device)
-  ChainDesc desc[TOPAY_CHAIN_SLOTS];
 };
