@@ -283,6 +283,11 @@ def main():
         o1.close()
         w1.close()
     stats = opt.stats()
+    # slot utilisation: device time of the candidates of one step summed (each is measured on the device's constant
+    # clock from its first to its last instruction) over the SIMD slots there are, beside the wall time of a step
+    slot_seconds = float(opt.elapsed_us().sum() * 1e-6)
+    simd_slots = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+    gate_timeouts = int(sum(o_.gate_timeouts() for o_ in opts))
     gate = opt.check_feasible()          # printConstraintsSituations over the batch (also part of every timed step)
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
@@ -291,7 +296,7 @@ def main():
     kms = float(np.mean(kernel_ms)) if depth == 1 else elapsed / args.steps * 1e3
     achieved = abytes / (kms * 1e-3) / 1e9
     if serial is not None:
-        serial["trajectories_per_s_per_gpu"] = B / (serial["ms_per_step"] * 1e-3)
+        serial["trajectories_per_s_per_gpu"] = (B - n_not_launched) / (serial["ms_per_step"] * 1e-3)
         serial["achieved_GBps"] = abytes / (serial["kernel_ms"] * 1e-3) / 1e9
         serial["frac"] = serial["achieved_GBps"] / HBM_PEAK_GBS
     # HBM-side bytes of one step from the committed PMC passes of this same command (tools/profile_round.sh; FETCH_SIZE
@@ -363,8 +368,15 @@ def main():
             "kernel_span_ms_each": [float(k) for k in kernel_ms], "steps_in_flight": depth,
             "serial_steps": serial,
             "algorithmic_bytes_per_step": abytes,
+            # work per slot: sum of the per-candidate device times of one step / SIMD slots; ms_per_step / this = how
+            # much longer a step takes than perfectly packed slots would (tail, hand-over between batches, LDS residency)
+            "slot_seconds_per_step": slot_seconds, "simd_slots": simd_slots,
+            "work_ms_per_slot": slot_seconds / simd_slots * 1e3,
+            "slot_utilisation": slot_seconds / simd_slots / (elapsed / args.steps),
         },
     }
+    if gate_timeouts:
+        out["error"] = f"dispatch gate timed out {gate_timeouts} time(s): a batch waited 120 s for its predecessor to become resident"
 
     if rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline and not hires:
         # CPU baseline: the oracle (a C++ port of the reference path; the reference itself needs Eigen/ROS/Boost and

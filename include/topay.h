@@ -185,8 +185,8 @@ topay_status topay_get_map_fields(topay_ctx* ctx, int map_id, double* esdf2d_inf
  *                    (row 0 = v, row 1 = omega, rows 3-9 = joints; col 0 = start, col 1 = end); NULL = zeros
  *   map_ids          map slot per candidate, NULL = all slot 0
  * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace.
- * The reference puts no bound on the number of pieces (moma_traj_opt.cpp:245, 300-321); this build solves up to 64
- * (a 96 s trajectory at the reference's 1.5 s sample_interval: one piece per lane, six system rows per lane).  A
+ * The reference puts no bound on the number of pieces (moma_traj_opt.cpp:245, 300-321); this build solves up to 128
+ * (a 192 s trajectory at the reference's 1.5 s sample_interval: what a four-wave workgroup holds in a compute unit's LDS).  A
  * candidate that needs more is reported as failed (success 0, cost NaN, n_pieces 0) without being launched and the
  * rest of the batch is solved normally; topay_get_batch's n_pieces lets the caller count such candidates. */
 topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len, const double* init_paths,
@@ -318,6 +318,12 @@ topay_status topay_get_x(topay_ctx* ctx, int i, int* n, double* x);
 topay_status topay_eval(topay_ctx* ctx, int stage, int i, const double* x, const double* alm_lambda,
                         const double* alm_rho, double* f, double* g, double* final_xy_error);
 
+/* Test hook: topay_eval by the kernel with `waves` wavefronts per trajectory (1: N <= 64, 2: N <= 64, 4: N <= 128)
+ * instead of the candidate's class default.  The evaluation is order-identical for any number of waves: f, g and the
+ * end-point error must come out bit for bit equal. */
+topay_status topay_eval_waves(topay_ctx* ctx, int stage, int i, int waves, const double* x, const double* alm_lambda,
+                              const double* alm_rho, double* f, double* g, double* final_xy_error);
+
 /* The spline of a given decision vector as candidate i's result.  MomaTrajOpt keeps the MINCO state of its last cost
  * evaluation and getTraj() returns it (moma_traj_opt.h:943-946; secondStageCostCallback, moma_traj_opt.cpp:885-955):
  * one stage-2 evaluation at x with the ALM state (lambda, rho), after which topay_get_result(s), topay_playback,
@@ -348,6 +354,15 @@ topay_status topay_get_trace(topay_ctx* ctx, int i, double* out);
 /* Test hook for the deterministic elementary functions of the solver (topay_amd/csrc/topay_math.h):
  * out[4i..] = sin(a_i), cos(a_i), atan2(a_i, b_i), sqrt(|a_i|)/(1+|b_i|). */
 topay_status topay_test_math(topay_ctx* ctx, int n, const double* a, const double* b, double* out4n);
+
+/* Launch class of a candidate with n_pieces pieces: waves per trajectory (1, 2 or 4) and decision-vector elements per
+ * thread of the kernel that solves and (topay_eval) evaluates it.  For parity tooling: the rounding of the solver's dot
+ * products depends on how the vectors are divided over the threads.  Any output pointer may be NULL. */
+topay_status topay_class_of(int n_pieces, int* waves, int* elements_per_thread, int* class_index);
+
+/* Device memory (bytes) of the batch resident in the context: every block topay_set_init_traj sized.  The variable-length
+ * blocks (L-BFGS history first of all) are packed by each candidate's own size, not strided by the longest member. */
+topay_status topay_workspace_bytes(topay_ctx* ctx, unsigned long long* bytes);
 
 /* Scheduling diagnostics: how often topay_optimize_async gave up waiting (120 s) for the previously issued batch to
  * become resident before issuing this context's batch (the dispatch gate only orders batches; results never depend on

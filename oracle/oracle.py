@@ -211,10 +211,11 @@ class Oracle:
         n = self.L.orc_mesh_traj(self.h, C.c_int(res), C.c_int(cap), _dp(parts), _dp(yaws), _dp(arcs))
         return parts[:n * 77].reshape(n, 11, 7), yaws[:n], arcs[:n]
 
-    def optimize_device_order(self, eval_fn, epl=12):
+    def optimize_device_order(self, eval_fn, epl=12, nw=1):
         """This restatement's solver logic with the vector arithmetic in the device's order and the cost / gradient from
         `eval_fn(stage, x, lam, rho) -> (f, g, fxe)` (the device's evaluation hook): must reproduce a device solve bit for
-        bit.  Returns success."""
+        bit.  epl / nw = decision-vector elements per thread and waves per trajectory of the kernel that solved the
+        candidate (topay_class_of; with one wave any epl >= the kernel's gives the same bits).  Returns success."""
         CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -227,8 +228,8 @@ class Oracle:
 
         self._cb = CB(cb)
         self.L.orc_optimize_device_order.restype = C.c_int
-        self.L.orc_optimize_device_order.argtypes = [C.c_void_p, C.c_int, CB, C.c_void_p]
-        return bool(self.L.orc_optimize_device_order(self.h, epl, self._cb, None))
+        self.L.orc_optimize_device_order.argtypes = [C.c_void_p, C.c_int, C.c_int, CB, C.c_void_p]
+        return bool(self.L.orc_optimize_device_order(self.h, epl, nw, self._cb, None))
 
     def traj_state(self, t):
         s = np.zeros(10)

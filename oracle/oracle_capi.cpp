@@ -126,13 +126,15 @@ int orc_optimize(void* hh) { return ((OracleHandle*)hh)->opt.optimize() ? 1 : 0;
 // Test tooling: this restatement's solver logic (L-BFGS, line search, ALM loop) with its vector arithmetic in the device's
 // order (epl = elements per lane, 12 covers every class) and the cost / gradient supplied by `fn` -- the device's
 // evaluation hook.  A device solve must come out bit for bit (tests/test_gpu_parity.py).
-int orc_optimize_device_order(void* hh, int epl, TrajOpt::ExternalEval fn, void* user) {
+int orc_optimize_device_order(void* hh, int epl, int nw, TrajOpt::ExternalEval fn, void* user) {
   TrajOpt& o = ((OracleHandle*)hh)->opt;
   o.ext_eval = fn;
   o.ext_user = user;
   g_device_epl = epl;
+  g_device_nw = (nw == 2 || nw == 4) ? nw : 1;
   const bool ok = o.optimize();
   g_device_epl = 0;
+  g_device_nw = 1;
   o.ext_eval = nullptr;
   o.ext_user = nullptr;
   return ok ? 1 : 0;

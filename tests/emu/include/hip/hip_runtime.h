@@ -49,16 +49,23 @@ struct Lane {
   ucontext_t ctx;
   char* stack = nullptr;
   bool done = false;
+  int wait_kind = 0;   // 0 runnable, 1 waiting for its wave's barrier generation to pass wait_gen, 2 for the block's
+  int wait_gen = 0;
 };
 struct State {
   uint3_emu tid{0, 0, 0}, bid{0, 0, 0};
   dim3 bdim, gdim;
   std::vector<Lane> lanes;
   int cur = 0;
+  int nl = 0;          // fibres of the running block
   ucontext_t sched;
   // exchange buffers for collectives: 2 phases x lanes x 16 bytes
   std::vector<unsigned char> xbuf;
   std::vector<int> phase;  // per lane
+  // barriers: a wave-level one per wavefront of 64 fibres (collectives, wave_barrier) and the block's (__syncthreads,
+  // s_barrier) -- a workgroup of several waves really runs its waves out of step between two block barriers
+  std::vector<int> wave_cnt, wave_gen;
+  int blk_cnt = 0, blk_gen = 0;
   unsigned char* dyn_smem = nullptr;
   std::function<void()> body;
   long barriers = 0;
@@ -73,28 +80,57 @@ inline void lane_entry() {
   s.lanes[s.cur].done = true;
   swapcontext(&s.lanes[s.cur].ctx, &s.sched);
 }
+// Barrier of the 64 fibres of the calling fibre's wavefront.  The last fibre to arrive goes on; the others are parked
+// until the wave's generation counter has moved (the scheduler does not switch to a parked fibre).
+inline void wave_barrier() {
+  State& s = S();
+  s.barriers++;
+  const int me = s.cur, w = me >> 6;
+  const int wsize = std::min(64, s.nl - 64 * w);
+  if (++s.wave_cnt[w] == wsize) {
+    s.wave_cnt[w] = 0;
+    s.wave_gen[w]++;
+    return;
+  }
+  s.lanes[me].wait_kind = 1;
+  s.lanes[me].wait_gen = s.wave_gen[w];
+  swapcontext(&s.lanes[me].ctx, &s.sched);
+}
+// Barrier of the whole block.
 inline void barrier() {
   State& s = S();
   s.barriers++;
-  int me = s.cur;
+  const int me = s.cur;
+  if (++s.blk_cnt == s.nl) {
+    s.blk_cnt = 0;
+    s.blk_gen++;
+    return;
+  }
+  s.lanes[me].wait_kind = 2;
+  s.lanes[me].wait_gen = s.blk_gen;
   swapcontext(&s.lanes[me].ctx, &s.sched);
-  // resumed: restore ids (scheduler sets cur/tid before switching in)
 }
 inline void run_block(unsigned bx, size_t shmem_bytes, const std::function<void()>& body) {
   State& s = S();
   const int nl = (int)(s.bdim.x * s.bdim.y * s.bdim.z);
+  s.nl = nl;
   s.bid = {bx, 0, 0};
   s.body = body;
   static const size_t STK = 1 << 20;
   if ((int)s.lanes.size() < nl) s.lanes.resize(nl);
   s.xbuf.assign((size_t)2 * nl * 16, 0);
   s.phase.assign(nl, 0);
+  s.wave_cnt.assign((nl + 63) / 64, 0);
+  s.wave_gen.assign((nl + 63) / 64, 0);
+  s.blk_cnt = 0;
+  s.blk_gen = 0;
   std::vector<unsigned char> smem(shmem_bytes + 64, 0);
   s.dyn_smem = smem.data();
   for (int l = 0; l < nl; l++) {
     Lane& L = s.lanes[l];
     if (!L.stack) L.stack = (char*)malloc(STK);
     L.done = false;
+    L.wait_kind = 0;
     getcontext(&L.ctx);
     L.ctx.uc_stack.ss_sp = L.stack;
     L.ctx.uc_stack.ss_size = STK;
@@ -103,19 +139,21 @@ inline void run_block(unsigned bx, size_t shmem_bytes, const std::function<void(
   }
   int remaining = nl;
   while (remaining > 0) {
-    int finished_this_sweep = 0, ran = 0;
+    int ran = 0;
     for (int l = 0; l < nl; l++) {
-      if (s.lanes[l].done) continue;
+      Lane& L = s.lanes[l];
+      if (L.done) continue;
+      if (L.wait_kind == 1 && s.wave_gen[l >> 6] == L.wait_gen) continue;
+      if (L.wait_kind == 2 && s.blk_gen == L.wait_gen) continue;
+      L.wait_kind = 0;
       s.cur = l;
       s.tid = {(unsigned)l % s.bdim.x, ((unsigned)l / s.bdim.x) % s.bdim.y, (unsigned)l / (s.bdim.x * s.bdim.y)};
-      swapcontext(&s.sched, &s.lanes[l].ctx);
+      swapcontext(&s.sched, &L.ctx);
       ran++;
-      if (s.lanes[l].done) finished_this_sweep++;
+      if (L.done) remaining--;
     }
-    remaining -= finished_this_sweep;
-    if (finished_this_sweep != 0 && finished_this_sweep != ran) {
-      fprintf(stderr, "[hip_emu] non-uniform barrier/exit in block %u (%d of %d lanes exited)\n", bx,
-              finished_this_sweep, ran);
+    if (ran == 0) {   // every live fibre waits for a barrier that cannot complete: some fibres skipped it or exited early
+      fprintf(stderr, "[hip_emu] deadlock in block %u: %d fibres wait at a barrier the others never reach\n", bx, remaining);
       abort();
     }
   }
@@ -132,7 +170,7 @@ inline T exchange(T v, int src, bool valid_src = true) {
   const int lanes = (int)(s.bdim.x * s.bdim.y * s.bdim.z);
   unsigned char* base = s.xbuf.data() + (size_t)ph * lanes * 16;
   memcpy(base + (size_t)me * 16, &v, sizeof(T));
-  barrier();
+  wave_barrier();
   T r = v;
   if (valid_src && src >= 0 && src < lanes) memcpy(&r, base + (size_t)src * 16, sizeof(T));
   return r;
@@ -185,7 +223,7 @@ inline unsigned long long __ballot(int pred) {
   unsigned char* base = s.xbuf.data() + (size_t)ph * lanes * 16;
   int p = pred ? 1 : 0;
   memcpy(base + (size_t)me * 16, &p, sizeof(int));
-  hip_emu::barrier();
+  hip_emu::wave_barrier();
   for (int l = 0; l < 64 && wbase + l < lanes; l++) {
     int q;
     memcpy(&q, base + (size_t)(wbase + l) * 16, sizeof(int));
@@ -218,8 +256,9 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   }
   return hip_emu::exchange(src, from);
 }
-inline void __builtin_amdgcn_wave_barrier() { hip_emu::barrier(); }
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __builtin_amdgcn_wave_barrier() { hip_emu::wave_barrier(); }
+inline void __builtin_amdgcn_s_barrier() { hip_emu::barrier(); }
+#define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline unsigned long long wall_clock64() { return 0; }
 inline unsigned long long __builtin_amdgcn_s_memtime() { return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count(); }

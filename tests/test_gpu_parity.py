@@ -182,12 +182,12 @@ def test_alm_rounds_match_oracle(cuboids_small):
 
 
 def test_more_than_32_pieces(cuboids_small):
-    """N = 33, 48, 64 (fourth launch class, six system rows per lane; the reference has no cap, moma_traj_opt.cpp:245,
-    300-321): packed initial guess, per-evaluation cost / gradient against the oracle at three kinds of points, a capped
-    solve with identical counters, and the same capped solve bit-identical to the CPU lane emulator.  N = 65 is reported
-    failed without a solve."""
+    """N = 33, 48, 64 (the classes of long candidates; the reference has no cap, moma_traj_opt.cpp:245, 300-321): packed
+    initial guess, per-evaluation cost / gradient against the oracle at three kinds of points, a capped solve with
+    identical counters, and the same capped solve bit-identical to the CPU lane emulator.  N = 129 is reported failed
+    without a solve (N = 96 and 128: tests/test_multiwave.py)."""
     cs = cuboids_small
-    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 67.0)]
+    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 134.5)]
     lens = np.array([len(p) for p in paths], dtype=np.int32)
     opt = api.MomaTrajOptBatch(device=0)
     set_map(opt, cs["world"])
@@ -341,7 +341,7 @@ def test_converged_solves_equal_oracle_solver_in_device_order():
     for b in range(len(lens)):
         o = orc.Oracle(m)
         o.set_init_traj(paths[offs[b]:offs[b + 1]])
-        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(o.N)[0])
         so = o.stats()
         assert okh == bool(ok[b]), b
         assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
@@ -378,7 +378,7 @@ def test_converged_solves_of_a_benchmark_slice_equal_oracle_solver_in_device_ord
             views[sc] = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
         o = orc.Oracle(views[sc])
         o.set_init_traj(tb.paths[offs[b]:offs[b + 1]])
-        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(o.N)[0])
         so = o.stats()
         assert okh == bool(ok[b]), b
         assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
@@ -464,7 +464,7 @@ def test_config5_high_resolution_esdf():
     for b in range(0, len(lens), 4):
         oh = orc.Oracle(m)
         oh.set_init_traj(paths[offs[b]:offs[b + 1]])
-        okh = oh.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho))
+        okh = oh.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(oh.N)[0])
         so = oh.stats()
         assert okh == bool(ok[b]) and (oh.get_x() == xs[b]).all() and (oh.alm_state() == alm[b]).all(), b
         assert [so["stage1_iters"], so["stage1_evals"], so["stage2_iters"], so["stage2_evals"], so["alm_outer"]] == \

@@ -1,0 +1,204 @@
+"""Several wavefronts per trajectory (topay_amd/csrc/topay_eval_mw.h): the workgroup of 2 or 4 waves that solves the long
+candidates (launch classes N <= 42 / 64 / 128).
+
+  * An evaluation is order-identical whatever the number of waves: for every N <= 64 the 2- and 4-wave kernels must
+    return, bit for bit, what the one-wave kernel returns (cost, gradient, end-point error) -- both stages, ordinary
+    points and the rare paths (joint velocity / acceleration rows, mean-time band, non-finite cost).
+  * N = 65..128 exists only on four waves (compact LDS layout from ~85 pieces on): per-evaluation parity against the
+    oracle, capped solves against the oracle, and whole solves against the oracle's solver logic in the device's
+    vector order (64 x waves threads, topay_class_of) fed with the device's evaluations -- bit for bit.
+The CPU half runs the kernel sources in the lane emulator (its waves really run out of step between workgroup
+barriers); the GPU half is the same on the MI355X, plus GPU == emulator.
+"""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, serpentine_path, set_map
+from oracle import oracle as orc
+from topay_amd import api
+
+
+def _points(o, n, N, rng):
+    x0 = o.get_x().copy()
+    yield x0
+    yield x0 + 0.04 * rng.standard_normal(n)
+    x = x0.copy()                       # rare paths: joint velocity / acceleration limits, mean-time band, folded arm
+    x[:N] -= 1.6
+    x[N - 1] += 2.5
+    x[3 * N - 1:] += np.tile([0.0, 1.5, 0.0, 2.4, 0.0, 1.9, 0.0], N - 1)
+    yield x
+
+
+def _check_eval(opt, cs, paths, rng, stages=(1, 2), vs_oracle=True):
+    """Every candidate of `paths`: all wave counts that hold it agree bit for bit, and agree with the oracle."""
+    Ns = opt.n_pieces()
+    for b, path in enumerate(paths):
+        N = int(Ns[b])
+        if N == 0:
+            continue
+        o = orc.Oracle(cs["map"])
+        n = o.set_init_traj(path)
+        assert o.N == N and np.allclose(opt.get_x(b), o.get_x(), rtol=0, atol=1e-12)
+        waves = (1, 2, 4) if N <= 64 else (4,)
+        for x in _points(o, n, N, rng):
+            for stage in stages:
+                lam, rho = [0.3, -0.2], [1e4, 2e4]
+                res = [opt.eval(stage, b, x, lam, rho, waves=w) for w in waves]
+                for r in res[1:]:
+                    assert r[0] == res[0][0] and (r[1] == res[0][1]).all() and (r[2] == res[0][2]).all(), (N, stage, waves)
+                fd, gd, ed = opt.eval(stage, b, x, lam, rho)            # the candidate's own launch class
+                assert fd == res[0][0] and (gd == res[0][1]).all() and (ed == res[0][2]).all()
+                if vs_oracle:
+                    o.set_alm(lam, rho)
+                    f, g = o.eval(stage, x)
+                    assert abs(f - fd) <= 1e-11 * abs(f), (N, stage)
+                    assert np.abs(g - gd).max() <= 1e-10 * np.abs(g).max(), (N, stage)
+
+
+def _capped_solve_vs_device_order(lib, cs, paths, s1_it, s2_it, outer):
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    p = api.default_params(api.load(lib))
+    p.s1_lbfgs.max_iterations = s1_it
+    p.s2_lbfgs.max_iterations = s2_it
+    p.alm_max_outer = outer
+    opt = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+    set_map(opt, cs["world"])
+    ok = opt.optimizeTraj(lens, np.concatenate(paths))
+    st, alm = opt.stats(), opt.alm_state()
+    xs = [opt.get_x(b) for b in range(len(paths))]
+    ev = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+    set_map(ev, cs["world"])
+    ev.set_init_traj(lens, np.concatenate(paths))
+    for b, path in enumerate(paths):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s1_max_iterations", s1_it)
+        o.set_param("s2_max_iterations", s2_it)
+        o.set_param("alm_max_outer", outer)
+        o.set_init_traj(path)
+        nw = opt.class_of(o.N)[0]
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=nw)
+        so = o.stats()
+        assert okh == bool(ok[b]) and [so[k] for k in api.STAT_KEYS] == list(st[b]), (b, o.N, nw)
+        assert (o.get_x() == xs[b]).all() and (o.alm_state() == alm[b]).all(), (b, o.N, nw)
+    return opt
+
+
+def test_class_table():
+    L = api.load(EMU_LIB)
+    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    assert [opt.class_of(N)[0] for N in (3, 10, 11, 21, 32)] == [1] * 5          # the common classes: one wave per trajectory
+    assert opt.class_of(128)[0] == 4 and opt.class_of(65)[0] == 4                  # N > 64 only exists on four waves
+    with pytest.raises(api.TopayError):
+        opt.class_of(129)
+    for N in (33, 42, 43, 64, 65, 128):
+        w, epl, k = opt.class_of(N)
+        assert 10 * N - 8 <= 64 * w * epl and 6 * N <= 64 * w * (epl // 2)         # the vectors and the system rows fit the threads
+
+
+def test_multiwave_evaluation_is_order_identical_on_cpu(cuboids_small):
+    """Kernel sources in the lane emulator: candidates of 4..11 pieces and a 33-piece one through the 1-, 2- and 4-wave
+    kernels (bit-identical), a 95-piece (full LDS layout) and a 126-piece one (compact layout) through four waves
+    against the oracle."""
+    cs = cuboids_small
+    rng = np.random.default_rng(5)
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    small = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in (0, 3, 5)]
+    emu.set_init_traj(np.array([len(p) for p in small], dtype=np.int32), np.concatenate(small))
+    _check_eval(emu, cs, small, rng)
+    long_ = [serpentine_path(L) for L in (34.0, 99.0, 131.5)]
+    emu.set_init_traj(np.array([len(p) for p in long_], dtype=np.int32), np.concatenate(long_))
+    assert list(emu.n_pieces()) == [33, 95, 126]
+    _check_eval(emu, cs, long_, rng, stages=(2,))
+
+
+def test_multiwave_solver_equals_oracle_in_device_order_on_cpu(cuboids_small):
+    """Capped solves of a 33-piece and a 95-piece candidate by the four-wave kernel (lane emulator) against the oracle's
+    solver logic with its vector arithmetic divided over 256 threads: iterate, multipliers and counters bit for bit."""
+    _capped_solve_vs_device_order(EMU_LIB, cuboids_small, [serpentine_path(34.0), serpentine_path(99.0)], 6, 4, 2)
+
+
+@pytest.mark.gpu
+def test_multiwave_evaluation_is_order_identical_on_gpu(cuboids_small):
+    cs = cuboids_small
+    rng = np.random.default_rng(6)
+    gpu = api.MomaTrajOptBatch(device=0)
+    set_map(gpu, cs["world"])
+    small = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in range(len(cs["lens"]))]
+    gpu.set_init_traj(cs["lens"], cs["paths"])
+    _check_eval(gpu, cs, small, rng)
+    long_ = [serpentine_path(L) for L in (20.0, 27.0, 34.0, 44.0, 50.0, 66.0, 67.0, 99.0, 120.0, 131.5, 133.0, 134.5)]
+    gpu.set_init_traj(np.array([len(p) for p in long_], dtype=np.int32), np.concatenate(long_))
+    N = gpu.n_pieces()
+    assert N[2] == 33 and N[5] == 64 and N[6] == 65 and N[10] == 128 and N[11] == 0     # 129 pieces: refused
+    _check_eval(gpu, cs, long_, rng)
+    # GPU == lane emulator, every bit, on a four-wave evaluation with the compact layout
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    emu.set_init_traj(np.array([len(long_[9])], dtype=np.int32), long_[9])
+    o = orc.Oracle(cs["map"])
+    n = o.set_init_traj(long_[9])
+    x = o.get_x() + 0.03 * rng.standard_normal(n)
+    for stage in (1, 2):
+        a, b_ = gpu.eval(stage, 9, x, [0.1, 0.2], [1e4, 3e4]), emu.eval(stage, 0, x, [0.1, 0.2], [1e4, 3e4])
+        assert a[0] == b_[0] and (a[1] == b_[1]).all() and (a[2] == b_[2]).all()
+
+
+@pytest.mark.gpu
+def test_long_candidates_up_to_128_pieces_on_gpu(cuboids_small):
+    """N = 96 and 128 (the reference has no bound on the pieces, moma_traj_opt.cpp:245, 300-321; this build's is 128):
+    capped solves against the oracle -- counters identical, iterate to 1e-7, getTraj coefficients -- and whole
+    solves of 33 / 64 / 96 / 128 pieces against the oracle's solver logic in the device's vector order, bit for bit."""
+    cs = cuboids_small
+    paths = [serpentine_path(L) for L in (100.0, 133.0, 134.5)]
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    p = api.default_params()
+    p.s2_lbfgs.max_iterations = 8
+    p.alm_max_outer = 1
+    cap = api.MomaTrajOptBatch(params=p, device=0)
+    set_map(cap, cs["world"])
+    ok = cap.optimizeTraj(lens, np.concatenate(paths))
+    N = cap.n_pieces()
+    assert list(N) == [96, 128, 0] and not ok[2] and np.isnan(cap.traj_cost[2])
+    st = cap.stats()
+    for k in range(2):
+        o = orc.Oracle(cs["map"])
+        o.set_param("s2_max_iterations", 8)
+        o.set_param("alm_max_outer", 1)
+        o.set_init_traj(paths[k])
+        o.optimize()
+        so = o.stats()
+        assert list(st[k]) == [so[key] for key in api.STAT_KEYS], (k, list(st[k]), so)
+        assert np.allclose(cap.get_x(k), o.get_x(), rtol=1e-7, atol=1e-8)
+        tr = cap.getTraj(k)
+        d, c, kn = o.get_traj()
+        assert np.allclose(tr["durations"], d, rtol=1e-8) and np.allclose(tr["knots_xy"], kn, atol=1e-7)
+        assert np.abs(tr["coeffs"] - c).max() <= 1e-6 * np.abs(c).max()
+    # whole solves (to the solver's own stop), device order
+    full = [serpentine_path(L) for L in (34.0, 66.0, 100.0, 133.0)]
+    opt = _capped_solve_vs_device_order(None, cs, full, 8000, 8000, 30)
+    assert list(opt.n_pieces()) == [33, 64, 96, 128]
+    assert opt.stats()[:, 4].min() > 30      # real stage-2 runs
+
+
+@pytest.mark.gpu
+def test_multiwave_capped_solve_is_bit_identical_to_emulator(cuboids_small):
+    """A 33-piece candidate on the four-wave kernel: stage 1 capped at five, stage 2 at three iterations, GPU vs lane
+    emulator -- trace of every evaluated cost, counters, iterate, coefficients."""
+    cs = cuboids_small
+    path = serpentine_path(34.0)
+    p = api.default_params()
+    p.s1_lbfgs.max_iterations = 5
+    p.s2_lbfgs.max_iterations = 3
+    p.alm_max_outer = 1
+    res = []
+    for lib in (None, EMU_LIB):
+        o2 = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+        set_map(o2, cs["world"])
+        o2.set_init_traj(np.array([len(path)], dtype=np.int32), path)
+        assert o2.class_of(int(o2.n_pieces()[0]))[0] == 4
+        o2.set_trace(64)
+        o2.optimize()
+        res.append((o2.stats(), o2.get_trace(0), o2.get_x(0), o2.getTraj(0)["coeffs"]))
+    g, e = res
+    assert (g[0] == e[0]).all() and (g[1] == e[1]).all() and (g[2] == e[2]).all() and (g[3] == e[3]).all()

@@ -121,6 +121,9 @@ def load(path=None):
     L.topay_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.topay_load_solution.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
     L.topay_gate_timeouts.argtypes = [C.c_void_p, c_ip]
+    L.topay_class_of.argtypes = [C.c_int, c_ip, c_ip, c_ip]
+    L.topay_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    L.topay_eval_waves.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
     L.topay_get_nmax.argtypes = [C.c_void_p, c_ip, c_ip]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
@@ -520,14 +523,19 @@ class MomaTrajOptBatch:
         return x
 
     # -- firstStageCostCallback / secondStageCostCallback (test hook)
-    def eval(self, stage, i, x, alm_lambda=None, alm_rho=None):
+    def eval(self, stage, i, x, alm_lambda=None, alm_rho=None, waves=None):
+        """(f, g, final_xy_error) of candidate i at x.  waves=1/2/4: by the kernel with that many wavefronts per trajectory
+        (test hook topay_eval_waves) instead of the candidate's class default."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         g = np.zeros_like(x)
         f = C.c_double(0)
         e = np.zeros(2)
         lam = None if alm_lambda is None else np.ascontiguousarray(alm_lambda, dtype=np.float64)
         rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
-        _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
+        if waves is None:
+            _chk(self.L, self.L.topay_eval(self.h, stage, i, _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
+        else:
+            _chk(self.L, self.L.topay_eval_waves(self.h, stage, i, int(waves), _dp(x), _dp(lam), _dp(rho), C.byref(f), _dp(g), _dp(e)))
         return f.value, g, e
 
     def load_solution(self, i, x, alm_lambda=None, alm_rho=None):
@@ -536,6 +544,17 @@ class MomaTrajOptBatch:
         lam = None if alm_lambda is None else np.ascontiguousarray(alm_lambda, dtype=np.float64)
         rho = None if alm_rho is None else np.ascontiguousarray(alm_rho, dtype=np.float64)
         _chk(self.L, self.L.topay_load_solution(self.h, i, _dp(x), _dp(lam), _dp(rho)))
+
+    def class_of(self, n_pieces):
+        """(waves per trajectory, elements per thread, class index) of the kernel that solves a candidate of n_pieces pieces."""
+        w, e, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        _chk(self.L, self.L.topay_class_of(int(n_pieces), C.byref(w), C.byref(e), C.byref(k)))
+        return w.value, e.value, k.value
+
+    def workspace_bytes(self):
+        b = C.c_ulonglong(0)
+        _chk(self.L, self.L.topay_workspace_bytes(self.h, C.byref(b)))
+        return int(b.value)
 
     def gate_timeouts(self):
         n = C.c_int(0)

@@ -316,6 +316,13 @@ __device__ __forceinline__ void esdf3d_finish(const DevMap& M, const Esdf3dReq& 
 // ---------------------------------------------------------------------------------------------
 struct EvalCtx {
   int lane, N, rows, n;
+  // several waves per trajectory (topay_eval_mw.h): thread index in the workgroup, wave index, small cross-wave scratch
+  int tid, wave;
+  lds_dp red;    // [8] partial sums of a workgroup reduction (two phases) | [64] pass totals | [2][NW][64] per-round costs | [NW] masks
+  lds_dp adj;    // [9][rows] right-hand sides / solution of the adjoint solve (== cL in the compact layout)
+  glb_dp coefg;  // HBM copy of the coefficients (the candidate's result block), read by the dJ/dT correction in the compact layout
+  int compact;
+  int cl_in_lds; // the coefficients of the last evaluation are still in C.cL (0: compact layout after a gradient phase -- they are in coefg)
   // LDS
   lds_dp cL;     // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
   lds_dp Tp;     // [5][N]     T, T^2..T^5
@@ -994,6 +1001,116 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Body of one even Simpson sample (i, j) of sweep 1: kinodynamic penalties, and in stage 2 the chassis ESDF query, the
+// manipulator block and the joint velocity / acceleration limits.  Outputs the per-sample gradient rows gB[12]
+// (theta orders 0-2, s orders 1-2, joints order 0), the sample's dJ/dT part, its positional gradient and its cost.
+// pcol = this lane's column of a [15][64] pass buffer (stash around the manipulator block, which needs the registers).
+// Shared by the one-wave and the several-waves evaluation: same arithmetic, same bits.
+// ---------------------------------------------------------------------------------------------
+template <int STAGE>
+__device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, int i, int j, double step, double half, double posx,
+                                            double posy, lds_dp pcol, const TOPAY_GLB DevMap* mp, double wM, double wA, double wD,
+                                            double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
+  const DevParams& P = g_P;
+  (void)C;
+  Basis B;
+  make_basis(j * half, B);
+  const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
+  const double real_alpha = 1.0 / TOPAY_K * ((double)j / 2.0);
+  double th0, th1, th2, th3, s0, sd1, sd2, sd3;
+  poly4(cL, rows, i, 0, B, th0, th1, th2, th3);
+  poly4(cL, rows, i, 1, B, s0, sd1, sd2, sd3);
+  cst = 0.0;
+  kinodynamic_block(P, wM, wA, wD, omg, step, real_alpha, th1, th2, th3, sd1, sd2, sd3, cst, gdTs, gB[1], gB[2],
+                    gB[3], gB[4]);
+  if (STAGE == 2) {
+    double sth, cth;
+    det_sincos(th0, &sth, &cth);
+    // chassis collision — moma_traj_opt.cpp:1304-1332
+    double d2, g2x, g2y;
+    {
+      const DevMap M = load_map(mp);
+      esdf2d_query(M, posx, posy, d2, g2x, g2y);
+    }
+    const double viola = P.chassis_colli_radius * 1.05 - d2;
+    if (viola > 0) {
+      double pe, pd;
+      smoothL1(viola, P.relu_mu, pe, pd);
+      const double sc = -omg * step * P.s2_collision_weight * pd;
+      gpx += sc * g2x;
+      gpy += sc * g2y;
+      gdTs += omg * P.s2_collision_weight * (pe * TOPAY_INV_K);
+      cst += omg * step * P.s2_collision_weight * pe;
+    }
+    // manipulator
+    double pos[10], q1[7];
+    pos[0] = posx; pos[1] = posy; pos[2] = th0;
+    double qacc = 0.0;  // moma_grad.tail(7) . dq
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+      double a0, a1, a2, a3;
+      poly4(cL, rows, i, 2 + q, B, a0, a1, a2, a3);
+      pos[3 + q] = a0;
+      q1[q] = a1;
+      // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the
+      // rare gradBeta rows are produced in the follow-up round when any lane is active)
+      const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
+      const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+      if (vDq > 0) {
+        double pe, pd;
+        smoothL1(vDq, P.relu_mu, pe, pd);
+        gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe * TOPAY_INV_K);
+        cst += omg * step * P.s2_mani_vel_weight * pe;
+        jva = true;
+      }
+      if (vD2q > 0) {
+        double pe, pd;
+        smoothL1(vD2q, P.relu_mu, pe, pd);
+        gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe * TOPAY_INV_K);
+        cst += omg * step * P.s2_mani_acc_weight * pe;
+        jva = true;
+      }
+      TOPAY_SCHED_FENCE();
+    }
+    // park the per-sample context in this lane's LDS column while the manipulator block runs: it needs nearly
+    // the whole register budget for the 12 sphere centres and their gradients
+    pcol[0 * 64] = th1;
+#pragma unroll
+    for (int q = 0; q < 7; q++) pcol[(1 + q) * 64] = q1[q];
+#pragma unroll
+    for (int v = 1; v < 5; v++) pcol[(7 + v) * 64] = gB[v];
+    pcol[12 * 64] = gdTs;
+    pcol[13 * 64] = cst;
+    ManiIn min_;
+#pragma unroll
+    for (int q = 0; q < 10; q++) min_.pos[q] = pos[q];
+    min_.omg = omg; min_.step = step; min_.sth = sth; min_.cth = cth;
+#ifdef TOPAY_STAMPS
+    const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    const ManiOut mo_ = manipulator_block(mp, min_);
+#ifdef TOPAY_STAMPS
+    if (C.stamps && C.lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
+#endif
+    const double* mg = mo_.g;
+    cst = pcol[13 * 64] + mo_.cost;
+    gdTs = pcol[12 * 64] + mo_.gdT;
+#pragma unroll
+    for (int v = 1; v < 5; v++) gB[v] = pcol[(7 + v) * 64];
+    gpx += mg[0];
+    gpy += mg[1];
+    gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
+    gdTs += mg[2] * pcol[0 * 64] * real_alpha;   // (1670)
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+      gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
+      qacc += mg[3 + q] * pcol[(1 + q) * 64];
+    }
+    gdTs += qacc * real_alpha;          // (1672)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The evaluation.  STAGE = 1: firstStageCostCallback; STAGE = 2: secondStageCostCallback.
 // RMAX = system rows per lane (1: N <= 10, 2: N <= 21, 3: N <= 32).  Returns f (wave-uniform); writes g[n].
 // ---------------------------------------------------------------------------------------------
@@ -1116,101 +1233,8 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #endif
     SUBSTAMP_BEGIN(C);
     if (act && !skip_body) {
-      Basis B;
-      make_basis(j * half, B);
-      const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
-      const double real_alpha = 1.0 / TOPAY_K * ((double)j / 2.0);
-      double th0, th1, th2, th3, s0, sd1, sd2, sd3;
-      poly4(cL, rows, i, 0, B, th0, th1, th2, th3);
-      poly4(cL, rows, i, 1, B, s0, sd1, sd2, sd3);
-      double cst = 0.0;
-      kinodynamic_block(P, wM, wA, wD, omg, step, real_alpha, th1, th2, th3, sd1, sd2, sd3, cst, gdTs, gB[1], gB[2],
-                        gB[3], gB[4]);
-      if (STAGE == 2) {
-        double sth, cth;
-        det_sincos(th0, &sth, &cth);
-        // chassis collision — moma_traj_opt.cpp:1304-1332
-        double d2, g2x, g2y;
-        {
-          const DevMap M = load_map(mp);
-          esdf2d_query(M, posx, posy, d2, g2x, g2y);
-        }
-        const double viola = P.chassis_colli_radius * 1.05 - d2;
-        if (viola > 0) {
-          double pe, pd;
-          smoothL1(viola, P.relu_mu, pe, pd);
-          const double sc = -omg * step * P.s2_collision_weight * pd;
-          gpx += sc * g2x;
-          gpy += sc * g2y;
-          gdTs += omg * P.s2_collision_weight * (pe * TOPAY_INV_K);
-          cst += omg * step * P.s2_collision_weight * pe;
-        }
-        // manipulator
-        double pos[10], q1[7];
-        pos[0] = posx; pos[1] = posy; pos[2] = th0;
-        double qacc = 0.0;  // moma_grad.tail(7) . dq
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-          double a0, a1, a2, a3;
-          poly4(cL, rows, i, 2 + q, B, a0, a1, a2, a3);
-          pos[3 + q] = a0;
-          q1[q] = a1;
-          // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the
-          // rare gradBeta rows are produced in the follow-up round when any lane is active)
-          const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
-          const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
-          if (vDq > 0) {
-            double pe, pd;
-            smoothL1(vDq, P.relu_mu, pe, pd);
-            gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe * TOPAY_INV_K);
-            cst += omg * step * P.s2_mani_vel_weight * pe;
-            jva = true;
-          }
-          if (vD2q > 0) {
-            double pe, pd;
-            smoothL1(vD2q, P.relu_mu, pe, pd);
-            gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe * TOPAY_INV_K);
-            cst += omg * step * P.s2_mani_acc_weight * pe;
-            jva = true;
-          }
-          TOPAY_SCHED_FENCE();
-        }
-        // park the per-sample context in this lane's LDS column while the manipulator block runs: it needs nearly
-        // the whole register budget for the 12 sphere centres and their gradients
-        pbuf[0 * 64 + lane] = th1;
-#pragma unroll
-        for (int q = 0; q < 7; q++) pbuf[(1 + q) * 64 + lane] = q1[q];
-#pragma unroll
-        for (int v = 1; v < 5; v++) pbuf[(7 + v) * 64 + lane] = gB[v];
-        pbuf[12 * 64 + lane] = gdTs;
-        pbuf[13 * 64 + lane] = cst;
-        ManiIn min_;
-#pragma unroll
-        for (int q = 0; q < 10; q++) min_.pos[q] = pos[q];
-        min_.omg = omg; min_.step = step; min_.sth = sth; min_.cth = cth;
-#ifdef TOPAY_STAMPS
-        const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
-        const ManiOut mo_ = manipulator_block(mp, min_);
-#ifdef TOPAY_STAMPS
-        if (C.stamps && lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
-#endif
-        const double* mg = mo_.g;
-        cst = pbuf[13 * 64 + lane] + mo_.cost;
-        gdTs = pbuf[12 * 64 + lane] + mo_.gdT;
-#pragma unroll
-        for (int v = 1; v < 5; v++) gB[v] = pbuf[(7 + v) * 64 + lane];
-        gpx += mg[0];
-        gpy += mg[1];
-        gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
-        gdTs += mg[2] * pbuf[0 * 64 + lane] * real_alpha;   // (1670)
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-          gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
-          qacc += mg[3 + q] * pbuf[(1 + q) * 64 + lane];
-        }
-        gdTs += qacc * real_alpha;          // (1672)
-      }
+      double cst;
+      sample_body<STAGE>(C, cL, rows, i, j, step, half, posx, posy, pbuf + lane, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
       cost_pen += cst;
     }
     SUBSTAMP_END(C, 12);  // sample body of lane 0

@@ -52,22 +52,42 @@ __global__ void k_init(DevBatch Bt, const double* paths, const long long* path_o
            Bt.x0 + (size_t)b * stride_n);
 }
 
-template <int RMAX>
-__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int init_stride_N) {
-  C.lane = threadIdx.x;
+// Where candidate b's variable-length blocks start: every per-candidate array is packed by the candidate's own size
+// (pieces before it: poff, decision-vector elements before it: noff), not strided by the longest member of the batch.
+__device__ __forceinline__ long long uniform_i64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
+template <int NW>
+__host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds, int compact) {
+  return NW == 1 ? lds_doubles(Nmax_lds) : lds_doubles_mw(Nmax_lds, NW, compact);
+}
+
+template <int RMAX, int NW>
+__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int compact) {
+  constexpr int NT = 64 * NW;
+  C.tid = threadIdx.x;
+  C.lane = threadIdx.x & 63;
+  C.wave = threadIdx.x >> 6;
   C.N = __builtin_amdgcn_readfirstlane(Bt.N[b]);  // wave-uniform: keep it (and what derives from it) in scalar registers
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
-  carve(C, TOPAY_LDS_PTR, Nmax_lds);
+  C.red = nullptr; C.adj = nullptr; C.compact = 0; C.cl_in_lds = 1;
+  if (NW == 1) carve(C, TOPAY_LDS_PTR, Nmax_lds);
+  else carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
   fill_power_table(C.pw, C.lane);
-  for (int t = C.lane; t < 27; t += 64) {
+  for (int t = C.tid; t < 27; t += NT) {
     C.hp[t] = Bt.head[(size_t)b * 27 + t];
     C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
   }
-  C.lu = (glb_dp)(Bt.lu + (size_t)b * 14 * 6 * Bt.Nmax);
-  C.sb_stride = TOPAY_EP * Bt.Nmax;
-  C.sbuf = (glb_dp)(Bt.sbuf + (size_t)b * 14 * C.sb_stride);
-  C.init_xy = (glb_cdp)(Bt.init_xy + (size_t)b * 2 * init_stride_N);
+  const long long po = uniform_i64(Bt.poff[b]);
+  C.lu = (glb_dp)(Bt.lu + 84 * po);
+  C.sb_stride = TOPAY_EP * C.N;
+  C.sbuf = (glb_dp)(Bt.sbuf + 14 * TOPAY_EP * po);
+  C.coefg = (glb_dp)(Bt.coef + 54 * po);
+  C.init_xy = (glb_cdp)(Bt.init_xy + (size_t)b * 2 * TOPAY_MAX_N);
   C.sx = Bt.start_xy[2 * b]; C.sy = Bt.start_xy[2 * b + 1];
   C.ex = Bt.goal_xy[2 * b];  C.ey = Bt.goal_xy[2 * b + 1];
   C.fxe0 = 0.0; C.fxe1 = 0.0;
@@ -80,18 +100,35 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
 #endif
 }
 
+// getTraj() state of the last evaluation (moma_traj_opt.h:943-946) into the candidate's result blocks
+template <int NW>
+__device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& Bt, int b) {
+  constexpr int NT = 64 * NW;
+  const int N = C.N, rows = C.rows;
+  const long long po = uniform_i64(Bt.poff[b]);
+  // (compact layout after a gradient phase: the coefficients already sit in the result block, C.cL holds the adjoint)
+  if (C.cl_in_lds) {
+    double* coef = Bt.coef + 54 * po;
+    for (int t = C.tid; t < 9 * rows; t += NT) coef[t] = C.cL[t];
+  }
+  for (int t = C.tid; t < N; t += NT) Bt.T[po + t] = C.Tp[t];
+  double* kn = Bt.knots + 2 * (po + b);
+  if (C.tid == 0) { kn[0] = C.sx; kn[1] = C.sy; }
+  for (int t = C.tid; t < 2 * N; t += NT) kn[2 + t] = C.pcs[2 * N + 2 + t];
+}
+
 // test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
-template <int RMAX>
-__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds,
-                                          int init_stride_N, int repeats) {
+template <int RMAX, int NW>
+__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int compact, int repeats) {
   const int b = Bt.order[blockIdx.x];
   const bool commit = (stage & 16) != 0;
   stage &= 15;
   EvalCtx C;
-  load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  C.x = (glb_cdp)(Bt.x + (size_t)b * Bt.nmax);
-  C.g = (glb_dp)(Bt.work + (size_t)b * 4 * Bt.nmax);
+  const long long no = uniform_i64(Bt.noff[b]);
+  C.x = (glb_cdp)(Bt.x + no);
+  C.g = (glb_dp)(Bt.work + 4 * no);
   C.lam0 = Bt.alm[4 * b]; C.lam1 = Bt.alm[4 * b + 1]; C.rho0 = Bt.alm[4 * b + 2]; C.rho1 = Bt.alm[4 * b + 3];
   __syncthreads();
   double f = 0.0;
@@ -102,29 +139,30 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
     GradGate gate;
     gate.always = !cost_only; gate.has_early = false; gate.finit = 0.0; gate.thr = -1.0e300; gate.early = 0.0;
     gate.early_ok = false; gate.skip_thr = 0.0;
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
-    else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+    if constexpr (NW == 1) {
+      if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
+      else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+    } else {
+      __syncthreads();
+      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW>(C, mp, gate);
+      else f = eval_cost_grad_mw<2, RMAX, NW>(C, mp, gate);
+    }
   }
-  if (C.lane == 0) {
+  if (C.tid == 0) {
     Bt.fout[b] = f;
     Bt.xyerr[2 * b] = C.fxe0;
     Bt.xyerr[2 * b + 1] = C.fxe1;
   }
   if (commit) {   // topay_load_solution: the spline of this x becomes the candidate's result, as after a solve that ended here
     __syncthreads();
-    const int N = C.N, rows = C.rows;
-    double* coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
-    for (int t = C.lane; t < 9 * rows; t += 64) coef[t] = C.cL[t];
-    if (C.lane < N) Bt.T[(size_t)b * Bt.Nmax + C.lane] = C.Tp[C.lane];
-    double* kn = Bt.knots + (size_t)b * 2 * (Bt.Nmax + 1);
-    if (C.lane == 0) { kn[0] = C.sx; kn[1] = C.sy; }
-    for (int t = C.lane; t < 2 * N; t += 64) kn[2 + t] = C.pcs[2 * N + 2 + t];
-    if (C.lane == 0) { Bt.cost[b] = f; Bt.success[b] = 1; }
+    store_result<NW>(C, Bt, b);
+    if (C.tid == 0) { Bt.cost[b] = f; Bt.success[b] = 1; }
   }
 }
 
-template <int RMAX>
-__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N, int b) {
+template <int RMAX, int NW>
+__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
+  constexpr int NT = 64 * NW;
   const unsigned long long t_begin = wall_clock64();
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
   // is resident, see topay_optimize_async
@@ -136,41 +174,37 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx<RMAX>(C, Bt, b, Nmax_lds, init_stride_N);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + lds_doubles(Nmax_lds);  // [8] past costs, then [48] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
+  const long long no = uniform_i64(Bt.noff[b]);
+  const int n = C.n;
   SolveIO S;
-  S.x = (glb_dp)(Bt.x + (size_t)b * Bt.nmax);
-  S.g = (glb_dp)(Bt.work + ((size_t)b * 4 + 0) * Bt.nmax);
-  S.xp = (glb_dp)(Bt.work + ((size_t)b * 4 + 1) * Bt.nmax);
-  S.gp = (glb_dp)(Bt.work + ((size_t)b * 4 + 2) * Bt.nmax);
-  S.d = (glb_dp)(Bt.work + ((size_t)b * 4 + 3) * Bt.nmax);
-  S.hist_s = (glb_dp)(Bt.hist_s + (size_t)b * Bt.hist_m * Bt.nmax);
-  S.hist_y = (glb_dp)(Bt.hist_y + (size_t)b * Bt.hist_m * Bt.nmax);
+  S.x = (glb_dp)(Bt.x + no);
+  S.g = (glb_dp)(Bt.work + 4 * no);
+  S.xp = (glb_dp)(Bt.work + 4 * no + n);
+  S.gp = (glb_dp)(Bt.work + 4 * no + 2 * (long long)n);
+  S.d = (glb_dp)(Bt.work + 4 * no + 3 * (long long)n);
+  S.hist_s = (glb_dp)(Bt.hist_s + (long long)Bt.hist_m * no);
+  S.hist_y = (glb_dp)(Bt.hist_y + (long long)Bt.hist_m * no);
   S.hist_ys = (glb_dp)(Bt.hist_ys + (size_t)b * Bt.hist_m);
   S.hist_al = (glb_dp)(Bt.hist_alpha + (size_t)b * Bt.hist_m);
-  S.nstride = Bt.nmax;
+  S.nstride = n;
   S.stats = (glb_ip)(Bt.stats + (size_t)b * 8);
   S.trace = Bt.trace ? (glb_dp)(Bt.trace + (size_t)b * Bt.trace_cap) : (glb_dp)nullptr;
   S.trace_cap = Bt.trace_cap;
   // x <- x0
   {
-    const double* x0 = Bt.x0 + (size_t)b * (10 * init_stride_N - 8);
-    for (int e = C.lane; e < C.n; e += 64) S.x[e] = x0[e];
+    const double* x0 = Bt.x0 + (size_t)b * (10 * TOPAY_MAX_N - 8);
+    for (int e = C.tid; e < C.n; e += NT) S.x[e] = x0[e];
   }
   int success = 0;
   double cost = 0.0;
-  solve_trajectory<RMAX>(C, mp, S, Bt.s1_past[b], pf, success, cost);
+  solve_trajectory<RMAX, NW>(C, mp, S, Bt.s1_past[b], pf, success, cost);
   // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
   __syncthreads();
-  const int N = C.N, rows = C.rows;
-  double* coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
-  for (int t = C.lane; t < 9 * rows; t += 64) coef[t] = C.cL[t];
-  if (C.lane < N) Bt.T[(size_t)b * Bt.Nmax + C.lane] = C.Tp[C.lane];
-  double* kn = Bt.knots + (size_t)b * 2 * (Bt.Nmax + 1);
-  if (C.lane == 0) { kn[0] = C.sx; kn[1] = C.sy; }
-  for (int t = C.lane; t < 2 * N; t += 64) kn[2 + t] = C.pcs[2 * N + 2 + t];
-  if (C.lane == 0) {
+  store_result<NW>(C, Bt, b);
+  if (C.tid == 0) {
     Bt.success[b] = success;
     Bt.cost[b] = cost;
     Bt.xyerr[2 * b] = C.fxe0;
@@ -193,8 +227,8 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX>
-__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int init_stride_N, int my_class) {
+template <int RMAX, int NW>
+__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int compact, int my_class) {
   const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
   for (int cls = my_class; cls >= lowest; cls--) {
@@ -203,61 +237,65 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
       int pos = 0;
       if (queued) {
         if (threadIdx.x == 0) pos = atomicAdd(B.queue_next + cls, 1);
-        pos = __shfl(pos, 0);
+        if (NW == 1) {
+          pos = __shfl(pos, 0);
+        } else {   // the position travels to the other waves through the first LDS word (nothing of a solve is live here)
+          TOPAY_LDS int* w0 = (TOPAY_LDS int*)TOPAY_LDS_PTR;
+          if (threadIdx.x == 0) w0[0] = pos;
+          __syncthreads();
+          pos = w0[0];
+          __syncthreads();
+        }
       } else {
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX>(B, maps, Nmax_lds, init_stride_N, B.order[off + pos]);
+      solve_one<RMAX, NW>(B, maps, Nmax_lds, compact, B.order[off + pos]);
       __syncthreads();
     }
   }
 }
 
-// Persistent launch: the grid is one workgroup per SIMD slot (or fewer), and every workgroup takes candidates from the
-// launch's queue -- positions of `order`, longest first -- until it is empty.  The hardware dispatcher places workgroups
-// in order on a fixed round-robin of XCDs / shader engines and stalls on a full one while others have room (about 10 %
-// of the slots stay empty when it has to place 8000 workgroups of unequal length); a resident wave that fetches its
-// next candidate itself leaves no slot idle and starts candidates strictly in queue order.  Which wave solves which
-// candidate is timing-dependent, the result of a candidate is not (nothing is shared between candidates).
-template <int RMAX>
-__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int init_stride_N) {
-  drain_queues<RMAX>(Bt, maps, Nmax_lds, init_stride_N, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
+// Persistent launch: the grid is one workgroup per SIMD slot (or fewer; a workgroup of NW waves takes NW slots), and
+// every workgroup takes candidates from the launch's queue -- positions of `order`, longest first -- until it is empty.
+// The hardware dispatcher places workgroups in order on a fixed round-robin of XCDs / shader engines and stalls on a
+// full one while others have room (about 10 % of the slots stay empty when it has to place 8000 workgroups of unequal
+// length); a resident workgroup that fetches its next candidate itself leaves no slot idle and starts candidates
+// strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
+// not (nothing is shared between candidates).
+template <int RMAX, int NW>
+__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact) {
+  drain_queues<RMAX, NW>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve1(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<1>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve2(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<2>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve3(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<3>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-// classes 4 and 5: four (N <= 42) and six (N <= 64) system rows per lane
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve4(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<4>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_solve6(DevBatch Bt, const DevMap* maps, int Nmax_lds) {
-  solve_body<6>(Bt, maps, Nmax_lds, TOPAY_MAX_N);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval1(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<1>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval2(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<2>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
-}
-
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval3(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<3>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
-}
-
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval4(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<4>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
-}
-__global__ void __launch_bounds__(64, TOPAY_WAVES_PER_EU) k_eval6(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) {
-  eval_body<6>(Bt, maps, stage, Nmax_lds, TOPAY_MAX_N, repeats);
-}
+// One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32 / 42 / 64.  Several waves per trajectory
+// (topay_eval_mw.h): k_solve<rows per thread>w<waves>, rows <= 64 x waves x rows per thread.
+#define TOPAY_SOLVE_KERNEL(NAME, R, W)                                                                              \
+  __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds, int compact) { \
+    solve_body<R, W>(Bt, maps, Nmax_lds, compact);                                                                  \
+  }
+#define TOPAY_EVAL_KERNEL(NAME, R, W)                                                                               \
+  __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds, int compact) { \
+    eval_body<R, W>(Bt, maps, stage, Nmax_lds, compact, repeats);                                                   \
+  }
+TOPAY_SOLVE_KERNEL(k_solve1, 1, 1)
+TOPAY_SOLVE_KERNEL(k_solve2, 2, 1)
+TOPAY_SOLVE_KERNEL(k_solve3, 3, 1)
+TOPAY_SOLVE_KERNEL(k_solve4, 4, 1)
+TOPAY_SOLVE_KERNEL(k_solve6, 6, 1)
+TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2)
+TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2)
+TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4)
+TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4)
+TOPAY_EVAL_KERNEL(k_eval1, 1, 1)
+TOPAY_EVAL_KERNEL(k_eval2, 2, 1)
+TOPAY_EVAL_KERNEL(k_eval3, 3, 1)
+TOPAY_EVAL_KERNEL(k_eval4, 4, 1)
+TOPAY_EVAL_KERNEL(k_eval6, 6, 1)
+TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2)
+TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2)
+TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4)
+TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4)
 
 // feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
 __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
@@ -269,8 +307,8 @@ __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps
     return;
   }
   FeasIO F;
-  F.coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
-  F.T = Bt.T + (size_t)b * Bt.Nmax;
+  F.coef = Bt.coef + 54 * Bt.poff[b];
+  F.T = Bt.T + Bt.poff[b];
   F.N = N;
   F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
   F.th0 = Bt.head[(size_t)b * 27];
@@ -301,8 +339,8 @@ __global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cse
     return;
   }
   FeasIO F;
-  F.coef = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;
-  F.T = Bt.T + (size_t)b * Bt.Nmax;
+  F.coef = Bt.coef + 54 * Bt.poff[b];
+  F.T = Bt.T + Bt.poff[b];
   F.N = N;
   F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
   F.th0 = Bt.head[(size_t)b * 27];
@@ -323,13 +361,13 @@ __global__ void k_gather_results(DevBatch Bt, int n, const int* idx, const int* 
   const int N = piece_off[k + 1] - piece_off[k];
   if (N <= 0) return;
   const int rows = 6 * N, p0 = piece_off[k];
-  const double* cm = Bt.coef + (size_t)b * 9 * 6 * Bt.Nmax;   // [9][rows], element d * rows + 6 p + k = coefficient of t^k
+  const double* cm = Bt.coef + 54 * Bt.poff[b];   // [9][rows], element d * rows + 6 p + k = coefficient of t^k
   for (int t = threadIdx.x; t < N * 54; t += blockDim.x) {
     const int p = t / 54, r = t - 54 * p, d = r / 6, kk = r - 6 * d;
     coeffs[(size_t)p0 * 54 + t] = cm[(size_t)d * rows + 6 * p + 5 - kk];   // per piece 9 x 6, highest order first
   }
-  for (int t = threadIdx.x; t < N; t += blockDim.x) durations[p0 + t] = Bt.T[(size_t)b * Bt.Nmax + t];
-  for (int t = threadIdx.x; t < 2 * (N + 1); t += blockDim.x) knots[2 * (size_t)(p0 + k) + t] = Bt.knots[(size_t)b * 2 * (Bt.Nmax + 1) + t];
+  for (int t = threadIdx.x; t < N; t += blockDim.x) durations[p0 + t] = Bt.T[Bt.poff[b] + t];
+  for (int t = threadIdx.x; t < 2 * (N + 1); t += blockDim.x) knots[2 * (size_t)(p0 + k) + t] = Bt.knots[2 * (Bt.poff[b] + b) + t];
 }
 
 // GridMap::isWholeBodyCollision for a batch of states
@@ -374,7 +412,14 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
-    HIPCHK(hipMalloc(&p, n));
+    {
+      hipError_t e_ = hipMalloc(&p, n);
+      if (e_ != hipSuccess) {
+        p = nullptr;
+        set_err("device allocation of " + std::to_string(n >> 20) + " MiB failed: " + hipGetErrorString(e_));
+        return TOPAY_ERR_NO_DEVICE;
+      }
+    }
     bytes = n;
     // debugging aid (TOPAY_POISON=<byte>): fill every fresh allocation, so that a read of memory nobody has written
     // shows up on every run instead of only when the allocator hands out dirty pages
@@ -404,12 +449,47 @@ struct DevBuf {
 // when the environment does not say otherwise.  With one wave per SIMD, four workgroups of the common classes (<= 21 /
 // 27 / 36 / 54 KB per wave) share a CU's 160 KB; the two rare classes of long candidates (<= 70 / 104 KB) cost their CU a
 // slot or two, which is why they are kept apart from each other.
-static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 15, 21, 32, 42, TOPAY_MAX_N};
+static const int kBucketMaxN[TOPAY_NBUCKET] = {10, 15, 21, 32, 42, 64, TOPAY_MAX_N};
 // Launch classes are finer than kernel templates where that saves LDS: the two-rows-per-lane kernel serves N <= 15 with
 // 27 KB and N <= 21 with 36 KB per workgroup (most candidates of the benchmark have 11..15 pieces).  LDS is what
 // limits how many workgroups a CU hosts beside a long candidate's: giving every class-1 workgroup the 38 KB of class 2
 // cost 8 % of the throughput, taking 9 KB from most of the two-rows workgroups pays the other way.
-static const int kBigFirst = TOPAY_NBUCKET - 2;   // the two classes of long candidates (72 / 106 KB of LDS)
+static const int kBigFirst = 4;   // the classes of long candidates (N > 32) start here
+
+// Kernel of a launch class: rows per thread and waves per trajectory select the template; the LDS is sized by the
+// longest candidate actually in the class.  The classes of long candidates have a one-wave and a several-waves variant
+// (TOPAY_MW_C4 / TOPAY_MW_C5 = waves per trajectory for N <= 42 / N <= 64; N <= 128 always runs on four waves).
+typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int, int);
+typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int, int);
+struct ClassDef {
+  int max_n, rmax, nw;
+  solve_kernel_t solve;
+  eval_kernel_t eval;
+};
+static const ClassDef* class_table() {
+  static const ClassDef* tab = [] {
+    static ClassDef t[TOPAY_NBUCKET] = {
+        {10, 1, 1, k_solve1, k_eval1}, {15, 2, 1, k_solve2, k_eval2}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
+        {42, 2, 4, k_solve2w4, k_eval2w4}, {64, 2, 4, k_solve2w4, k_eval2w4}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
+    auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    const int w4 = env_nw("TOPAY_MW_C4", 4), w5 = env_nw("TOPAY_MW_C5", 4);
+    if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4};
+    else if (w4 == 2) t[4] = {42, 2, 2, k_solve2w2, k_eval2w2};
+    if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6};
+    else if (w5 == 2) t[5] = {64, 3, 2, k_solve3w2, k_eval3w2};
+    return t;
+  }();
+  return tab;
+}
+static const int kLdsDoublesPerCU = 160 * 1024 / 8;
+// compact LDS layout (topay_eval_mw.h) when the full one does not fit a compute unit
+static int class_compact(const ClassDef& cd, int nm) {
+  return cd.nw > 1 && lds_doubles_mw(nm, cd.nw, 0) + 8 + 48 > kLdsDoublesPerCU ? 1 : 0;
+}
+static size_t class_lds_bytes(const ClassDef& cd, int nm) {
+  const int d = cd.nw == 1 ? lds_doubles(nm) : lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
+  return (size_t)(d + 8 + 48) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [48]
+}
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
 // (the runtime reads the variable once, at its first call).  A caller that initialises HIP first should export
@@ -441,7 +521,11 @@ struct topay_ctx {
   DevBuf dmaps;
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
   // batch
-  int B = 0, Nmax = 0, nmax = 0, total_states = 0, Pmax = 0;
+  int B = 0, Nmax = 0, total_states = 0, Pmax = 0;
+  // pieces / decision-vector elements of the candidates before b (packed per-candidate blocks, DevBatch::poff / noff)
+  std::vector<long long> h_poff, h_noff;
+  DevBuf poff, noff;
+  size_t workspace_bytes = 0;   // device memory of the resident batch (topay_workspace_bytes)
   // per-trajectory N (0 = not representable, skipped); launch buckets by N (LDS is sized per bucket)
   std::vector<int> hN;
   static constexpr int NBUCKET = TOPAY_NBUCKET;
@@ -699,7 +783,7 @@ void topay_destroy(topay_ctx* c) {
   (void)hipSetDevice(c->device);
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
-                    &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats,
+                    &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->poff, &c->noff, &c->success, &c->cost, &c->stats,
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
   for (DevBuf* b : bufs) b->release();
@@ -760,8 +844,6 @@ static int bucket_of(int N) {
   if (force >= 2 && force <= topay_ctx::NBUCKET) k0 = std::max(k0, force - 1);
   return k0;
 }
-// + past-cost ring [8] + two-loop alpha ring [256] + the solver state parked across an evaluation [48]
-static size_t solve_lds_bytes(int Nmax) { return (size_t)(lds_doubles(Nmax) + 8 + 48) * sizeof(double); }
 
 static bool batch_done(topay_ctx* p);
 // what the __constant__ parameter block of each device holds (last push)
@@ -1093,7 +1175,13 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   }
   if (Nmax == 0) { set_err("every trajectory needs more pieces than TOPAY_MAX_N"); return TOPAY_ERR_TOO_MANY_PIECES; }
   c->Nmax = Nmax;
-  c->nmax = 10 * Nmax - 8;
+  c->h_poff.assign((size_t)batch + 1, 0);
+  c->h_noff.assign((size_t)batch + 1, 0);
+  for (int b = 0; b < batch; b++) {
+    c->h_poff[b + 1] = c->h_poff[b] + c->hN[b];
+    c->h_noff[b + 1] = c->h_noff[b] + (c->hN[b] > 0 ? 10 * c->hN[b] - 8 : 0);
+  }
+  const size_t P = (size_t)c->h_poff[batch], NN = (size_t)c->h_noff[batch];
   const int m = std::max(c->hp.s1_lbfgs.mem_size, c->hp.s2_lbfgs.mem_size);
   // launch order: longest trajectories first inside each row class (tail latency)
   std::vector<int> idx(batch);
@@ -1113,28 +1201,43 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
     ord.resize(batch, 0);
     HIPCHK(memcpy_sync(c, c->order.p, ord.data(), (size_t)batch * 4, hipMemcpyHostToDevice));
   }
-  ENS(x, (size_t)batch * c->nmax * 8);
-  ENS(work, (size_t)batch * 4 * c->nmax * 8);
-  ENS(hist_s, (size_t)batch * m * c->nmax * 8);
-  ENS(hist_y, (size_t)batch * m * c->nmax * 8);
+  ENS(poff, ((size_t)batch + 1) * 8);
+  ENS(noff, ((size_t)batch + 1) * 8);
+  HIPCHK(memcpy_sync(c, c->poff.p, c->h_poff.data(), ((size_t)batch + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->noff.p, c->h_noff.data(), ((size_t)batch + 1) * 8, hipMemcpyHostToDevice));
+  // every block sized by the candidates' own pieces / decision vectors (the history, 2 m n doubles per candidate, is
+  // by far the largest: 0.4 MB at the benchmark's mean of 11 pieces, 5 MB at 128)
+  ENS(x, NN * 8);
+  ENS(work, 4 * NN * 8);
+  ENS(hist_s, (size_t)m * NN * 8);
+  ENS(hist_y, (size_t)m * NN * 8);
   ENS(hist_ys, (size_t)batch * m * 8);
   ENS(hist_alpha, (size_t)batch * m * 8);
-  ENS(lu, (size_t)batch * 14 * 6 * Nmax * 8);
+  ENS(lu, 84 * P * 8);
   ENS(success, (size_t)batch * 4);
   ENS(cost, (size_t)batch * 8);
   ENS(stats, (size_t)batch * 8 * 4);
   ENS(xyerr, (size_t)batch * 2 * 8);
-  ENS(coef, (size_t)batch * 9 * 6 * Nmax * 8);
-  ENS(T, (size_t)batch * Nmax * 8);
-  ENS(knots, (size_t)batch * 2 * (Nmax + 1) * 8);
+  ENS(coef, 54 * P * 8);
+  ENS(T, P * 8);
+  ENS(knots, 2 * (P + batch) * 8);
   ENS(alm, (size_t)batch * 4 * 8);
   ENS(fout, (size_t)batch * 8);
-  ENS(sbuf, (size_t)batch * 14 * TOPAY_EP * Nmax * 8);
+  ENS(sbuf, 14 * TOPAY_EP * P * 8);
   ENS(elapsed, (size_t)batch * 8);
   ENS(startus, (size_t)batch * 8);
   ENS(hwid, (size_t)batch * 4);
 #undef ENS
-  d.Nmax = Nmax; d.nmax = c->nmax; d.hist_m = m;
+  {
+    DevBuf* all[] = {&c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past, &c->map_id, &c->head, &c->tail,
+                     &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->order, &c->poff, &c->noff, &c->x, &c->work, &c->hist_s, &c->hist_y,
+                     &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats, &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm,
+                     &c->fout, &c->sbuf, &c->elapsed, &c->startus, &c->hwid};
+    c->workspace_bytes = 0;
+    for (DevBuf* q : all) c->workspace_bytes += q->bytes;
+  }
+  d.hist_m = m;
+  d.poff = c->poff.as<long long>(); d.noff = c->noff.as<long long>();
   d.x = c->x.as<double>(); d.work = c->work.as<double>();
   d.hist_s = c->hist_s.as<double>(); d.hist_y = c->hist_y.as<double>();
   d.hist_ys = c->hist_ys.as<double>(); d.hist_alpha = c->hist_alpha.as<double>();
@@ -1165,66 +1268,70 @@ topay_status topay_reset(topay_ctx* c) {
 }  // extern "C"
 
 // Persistent grids: the slots are divided between the classes in proportion to an estimate of their work
-// (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly), so that the launches of
-// one batch together ask for exactly the slots the device has and none of their workgroups waits in the dispatcher.
+// (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly; a several-waves workgroup
+// occupies NW slots for 1 / speed-up of the time), so that the launches of one batch together ask for exactly the
+// slots the device has and none of their workgroups waits in the dispatcher.  share[k] is in SLOTS.
 static void compute_shares(topay_ctx* c, int slots, int* share) {
+  const ClassDef* ct = class_table();
   double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    for (int b : c->cls[k]) wk[k] += std::pow((double)c->hN[b], 1.5);
+    const double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
+    for (int b : c->cls[k]) wk[k] += slot_cost * std::pow((double)c->hN[b], 1.5);
     wt += wk[k];
   }
   int used = 0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    const int nk = (int)c->cls[k].size();
-    share[k] = nk == 0 ? 0 : std::min(nk, std::max(1, (int)std::floor(wk[k] / wt * slots)));
-    used += share[k];
+    const int nk = (int)c->cls[k].size(), nw = ct[k].nw;
+    int sh = nk == 0 ? 0 : std::min(nk * nw, std::max(nw, (int)std::floor(wk[k] / wt * slots)));
+    sh -= sh % nw;
+    share[k] = sh;
+    used += sh;
   }
   for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
-    const int kk = k % topay_ctx::NBUCKET;
-    if (share[kk] > 0 && share[kk] < (int)c->cls[kk].size()) { share[kk]++; used++; }
-  }
-  // The two classes of long candidates share one pool of workgroups (a class-6 workgroup also serves class 4, not the
-  // other way round): the longest class first gets one workgroup per candidate as far as the pool goes, so that no
-  // 43..64-piece candidate -- the longest single solves of a batch -- queues behind another one.
-  static const bool pool_big = [] { const char* e = getenv("TOPAY_BIG_POOL"); return e && e[0] == '1'; }();
-  if (pool_big && share[kBigFirst + 1] > 0) {
-    const int pool = share[kBigFirst] + share[kBigFirst + 1], n3 = (int)c->cls[kBigFirst].size(), n4 = (int)c->cls[kBigFirst + 1].size();
-    share[kBigFirst + 1] = std::min(n4, pool - (n3 > 0 ? 1 : 0));
-    share[kBigFirst] = std::min(n3, pool - share[kBigFirst + 1]);
+    const int kk = k % topay_ctx::NBUCKET, nw = ct[kk].nw;
+    if (share[kk] > 0 && share[kk] + nw <= (int)c->cls[kk].size() * nw && used + nw <= slots) { share[kk] += nw; used += nw; }
   }
 }
 
-// Kernel of launch class k (rows per lane 1 / 2 / 3 / 4 / 6).  The class index selects the template -- also when the
-// diagnostic TOPAY_FORCE_CLASS routes small candidates through a larger class -- and the LDS is sized by the longest
-// candidate actually in the class.
-typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
-typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
-static const solve_kernel_t kSolveKernels[TOPAY_NBUCKET] = {k_solve1, k_solve2, k_solve2, k_solve3, k_solve4, k_solve6};
-static const eval_kernel_t kEvalKernels[TOPAY_NBUCKET] = {k_eval1, k_eval2, k_eval2, k_eval3, k_eval4, k_eval6};
-
-// Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most its class can ask
+// Dynamic LDS above the 64 KB default needs the attribute; it is set once per device to the most a kernel can ask
 // for (the launch itself passes the size it needs), not per launch: two host threads launching different contexts
 // would otherwise interleave set(small), set(large), launch(large).
 static std::once_flag g_attr_once[16];
 static hipError_t g_attr_err[16];
 static hipError_t set_kernel_attributes(int device) {
   std::call_once(g_attr_once[device % 16], [device] {
+    (void)device;
     hipError_t e = hipSuccess;
+    const ClassDef* ct = class_table();
     for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
-      const int lds = (int)solve_lds_bytes(kBucketMaxN[k]);
-      e = hipFuncSetAttribute((const void*)kSolveKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kEvalKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      int lds = 0;   // classes that share a kernel: the largest request
+      for (int k2 = 0; k2 < TOPAY_NBUCKET; k2++)
+        if (ct[k2].solve == ct[k].solve) lds = std::max(lds, (int)class_lds_bytes(ct[k2], ct[k2].max_n));
+      e = hipFuncSetAttribute((const void*)ct[k].solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ct[k].eval, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     g_attr_err[device % 16] = e;
   });
   return g_attr_err[device % 16];
 }
 
-template <typename KF, typename... Args>
-static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kernels, Args... args) {
+// Lowest class whose queue a workgroup of class k may go on with once its own is empty: a smaller class its kernel
+// covers AND whose candidates it solves to the same bits (the division of the L-BFGS vectors over the threads depends on
+// the waves per trajectory, so only classes with the same number of waves), and never across the long / common boundary
+// (a resident workgroup of a long class holds LDS or whole compute units the common classes' workgroups want).
+static int steal_floor(int k) {
+  const ClassDef* ct = class_table();
+  int lo = k;
+  while (lo > 0 && ct[lo - 1].nw == ct[k].nw && ((lo - 1 >= kBigFirst) == (k >= kBigFirst))) lo--;
+  return lo;
+}
+
+template <bool EVAL, typename... Args>
+static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) {
   // One launch per N-bucket, each on its own stream so that the tail of one bucket overlaps the others.
   // Longest jobs first.  The context's main stream waits for all of them (events), so the caller's
   // ev0/ev1 pair on the main stream brackets the whole solve.
+  const ClassDef* ct = class_table();
   int launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
@@ -1244,6 +1351,10 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
     if (nk == 0) continue;
     int nm = 0;
     for (int b : v) nm = std::max(nm, c->hN[b]);
+    // classes that may take over each other's queues run the same kernel: its LDS must hold the longest candidate of any of them
+    if (persistent && c->steal)
+      for (int k2 = steal_floor(k); k2 < k; k2++)
+        for (int b : c->cls[k2]) nm = std::max(nm, c->hN[b]);
     DevBatch d = c->db;
     d.order = c->db.order + off;
     int grid = nk;
@@ -1251,24 +1362,22 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, const KF* kern
       d.order = c->db.order;
       d.queue_next = c->qnext.as<int>();
       d.queue_class = k;
-      // A workgroup whose own queue is empty goes on with the queues of the smaller classes -- but the workgroups of
-      // the two classes of long candidates (70 / 104 KB of LDS, a CU has 160 KB for its four SIMDs) only with each
-      // other's: while they are resident their CU cannot fill its other SIMDs, so they should leave as soon as the
-      // long candidates are done and make room for workgroups (of the next batch) that need a quarter of that.
-      d.queue_lowest = c->steal ? (k >= kBigFirst ? kBigFirst : 0) : k;
+      d.queue_lowest = c->steal ? steal_floor(k) : k;
       int o2 = 0;
       for (int kk = topay_ctx::NBUCKET - 1; kk >= 0; kk--) {   // `order` holds the classes largest first
         d.queue_off[kk] = o2;
         d.queue_count[kk] = (int)c->cls[kk].size();
         o2 += d.queue_count[kk];
       }
-      grid = share[k];
+      grid = std::max(1, share[k] / ct[k].nw);
     }
     off += nk;
-    const size_t lds = solve_lds_bytes(nm);
+    const size_t lds = class_lds_bytes(ct[k], nm);
+    const int compact = class_compact(ct[k], nm);
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
-    hipLaunchKernelGGL(kernels[k], dim3(grid), dim3(64), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+    if constexpr (EVAL) hipLaunchKernelGGL(ct[k].eval, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm, compact);
+    else hipLaunchKernelGGL(ct[k].solve, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, nm, compact);
     HIPCHK(hipGetLastError());
     if (st != c->stream) HIPCHK(hipEventRecord(c->bevent[k], st));
     launches++;
@@ -1324,7 +1433,7 @@ topay_status topay_optimize_async(topay_ctx* c) {
     // long candidates need 70 / 104 KB of LDS and may not find a compute unit with that much free until the previous
     // batch's tail -- holding the whole next batch back for them leaves the rest of the device idle meanwhile.
     c->n_gate = ng;
-    c->db.gate_maxN = kBucketMaxN[kBigFirst - 1];
+    c->db.gate_maxN = kBucketMaxN[kBigFirst - 1];   // (the common classes: up to 32 pieces)
     void* dp = nullptr;
     HIPCHK(hipHostGetDevicePointer(&dp, c->h_started, 0));
     c->db.started = (int*)dp;
@@ -1334,7 +1443,7 @@ topay_status topay_optimize_async(topay_ctx* c) {
   // candidates that were not launched keep success = 0 and cost = NaN
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
-  topay_status s = launch_classes(c, c->persistent, kSolveKernels);
+  topay_status s = launch_classes<false>(c, c->persistent);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   c->pending = true;
@@ -1363,7 +1472,7 @@ topay_status topay_optimize(topay_ctx* c) {
 
 topay_status topay_get_nmax(topay_ctx* c, int* nmax, int* Nmax) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
-  if (nmax) *nmax = c->nmax;
+  if (nmax) *nmax = 10 * c->Nmax - 8;
   if (Nmax) *Nmax = c->Nmax;
   return TOPAY_OK;
 }
@@ -1393,8 +1502,8 @@ topay_status topay_playback(topay_ctx* c, int i, int n_times, const double* time
   if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B || n_times < 0 || (n_times > 0 && (!times || !states))) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
-  std::vector<double> hT((size_t)c->Nmax);
-  HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> hT((size_t)std::max(1, c->hN[i]));
+  if (c->hN[i] > 0) HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + c->h_poff[i], (size_t)c->hN[i] * 8, hipMemcpyDeviceToHost));
   double t = 0.0;
   for (int k = 0; k < c->hN[i]; k++) t += hT[k];
   if (!(t > 0.0 && t < 1.0e4)) t = 0.0;
@@ -1465,8 +1574,8 @@ topay_status topay_mesh_traj(topay_ctx* c, int i, const topay_mesh_params_t* mes
   if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B || !mesh || res <= 0 || cap_states < res + 1 || !parts || !yaws || !arc_lengths || !n_states) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
-  std::vector<double> hT((size_t)c->Nmax);
-  HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + (size_t)i * c->Nmax, hT.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> hT((size_t)std::max(1, c->hN[i]));
+  if (c->hN[i] > 0) HIPCHK(memcpy_sync(c, hT.data(), c->T.as<double>() + c->h_poff[i], (size_t)c->hN[i] * 8, hipMemcpyDeviceToHost));
   double T = 0.0;
   for (int k = 0; k < c->hN[i]; k++) T += hT[k];
   if (!(T > 0.0 && T < 1.0e4)) { *n_states = 0; return TOPAY_OK; }
@@ -1610,11 +1719,11 @@ topay_status topay_connect_collision(topay_ctx* c, int map_id, int n_edges, cons
 topay_status topay_get_total_durations(topay_ctx* c, double* total) {
   if (!c || !c->have_traj || !total) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
-  std::vector<double> hT((size_t)c->B * c->Nmax);
-  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> hT((size_t)c->h_poff[c->B] + 1);
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, (size_t)c->h_poff[c->B] * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < c->B; b++) {
     double t = 0.0;
-    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)b * c->Nmax + i];  // PolyTrajectory::getTotalDuration, minco.hpp:304-313
+    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)c->h_poff[b] + i];  // PolyTrajectory::getTotalDuration, minco.hpp:304-313
     total[b] = c->hN[b] > 0 ? t : 0.0 / 0.0;
   }
   return TOPAY_OK;
@@ -1650,17 +1759,17 @@ topay_status topay_get_result(topay_ctx* c, int i, int* success, double* cost, i
   if (success) HIPCHK(memcpy_sync(c, success, c->success.as<int>() + i, 4, hipMemcpyDeviceToHost));
   if (cost) HIPCHK(memcpy_sync(c, cost, c->cost.as<double>() + i, 8, hipMemcpyDeviceToHost));
   if (n_pieces) *n_pieces = N;
-  if (durations) HIPCHK(memcpy_sync(c, durations, c->T.as<double>() + (size_t)i * c->Nmax, (size_t)N * 8, hipMemcpyDeviceToHost));
+  if (durations) HIPCHK(memcpy_sync(c, durations, c->T.as<double>() + c->h_poff[i], (size_t)N * 8, hipMemcpyDeviceToHost));
   if (coeffs) {
     std::vector<double> cm((size_t)9 * rows);
-    HIPCHK(memcpy_sync(c, cm.data(), c->coef.as<double>() + (size_t)i * 9 * 6 * c->Nmax, cm.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(c, cm.data(), c->coef.as<double>() + 54 * c->h_poff[i], cm.size() * 8, hipMemcpyDeviceToHost));
     // getTraj(): per piece the 6x9 block transposed, highest order first — minco.hpp:908-921
     for (int p = 0; p < N; p++)
       for (int d = 0; d < 9; d++)
         for (int k = 0; k < 6; k++) coeffs[((size_t)p * 9 + d) * 6 + k] = cm[(size_t)d * rows + 6 * p + 5 - k];
   }
   if (knots_xy)
-    HIPCHK(memcpy_sync(c, knots_xy, c->knots.as<double>() + (size_t)i * 2 * (c->Nmax + 1), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(c, knots_xy, c->knots.as<double>() + 2 * (c->h_poff[i] + i), (size_t)2 * (N + 1) * 8, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1740,21 +1849,35 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
   if (n) *n = nn;
   if (x) {
     // after optimize: the final iterate; before: the packed initial guess
-    if (c->solved) HIPCHK(memcpy_sync(c, x, c->x.as<double>() + (size_t)i * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+    if (c->solved) HIPCHK(memcpy_sync(c, x, c->x.as<double>() + c->h_noff[i], (size_t)nn * 8, hipMemcpyDeviceToHost));
     else HIPCHK(memcpy_sync(c, x, c->x0.as<double>() + (size_t)i * (10 * TOPAY_MAX_N - 8), (size_t)nn * 8, hipMemcpyDeviceToHost));
   }
   return TOPAY_OK;
 }
 
+// Kernel for a forced number of waves per trajectory (test hook topay_eval_waves): the smallest template that holds N.
+static bool class_for_waves(int N, int nw, ClassDef& out) {
+  static const ClassDef w1[] = {{10, 1, 1, k_solve1, k_eval1}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
+                                {42, 4, 1, k_solve4, k_eval4}, {64, 6, 1, k_solve6, k_eval6}};
+  static const ClassDef w2[] = {{42, 2, 2, k_solve2w2, k_eval2w2}, {64, 3, 2, k_solve3w2, k_eval3w2}};
+  static const ClassDef w4[] = {{85, 2, 4, k_solve2w4, k_eval2w4}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
+  const ClassDef* t = nw == 1 ? w1 : (nw == 2 ? w2 : (nw == 4 ? w4 : nullptr));
+  const int cnt = nw == 1 ? 5 : 2;
+  if (!t) return false;
+  for (int k = 0; k < cnt; k++)
+    if (N <= t[k].max_n) { out = t[k]; return true; }
+  return false;
+}
+
 static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
-                             double* f, double* g, double* final_xy_error, bool commit) {
+                             double* f, double* g, double* final_xy_error, bool commit, int force_nw = 0) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (i < 0 || i >= c->B || (stage != 1 && stage != 2) || !x) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   const int N = c->hN[i], nn = 10 * N - 8;
   if (N == 0) return TOPAY_ERR_TOO_MANY_PIECES;
-  HIPCHK(memcpy_sync(c, c->x.as<double>() + (size_t)i * c->nmax, x, (size_t)nn * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->x.as<double>() + c->h_noff[i], x, (size_t)nn * 8, hipMemcpyHostToDevice));
   double alm[4] = {alm_lambda ? alm_lambda[0] : c->hp.alm_init_lambda[0], alm_lambda ? alm_lambda[1] : c->hp.alm_init_lambda[1],
                    alm_rho ? alm_rho[0] : c->hp.alm_init_rho[0], alm_rho ? alm_rho[1] : c->hp.alm_init_rho[1]};
   HIPCHK(memcpy_sync(c, c->alm.as<double>() + (size_t)i * 4, alm, 32, hipMemcpyHostToDevice));
@@ -1765,15 +1888,18 @@ static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, co
   HIPCHK(memcpy_sync(c, tmp.p, &i, 4, hipMemcpyHostToDevice));
   DevBatch d = c->db;
   d.order = tmp.as<int>();
-  const size_t lds = solve_lds_bytes(N);
+  ClassDef cd = class_table()[bucket_of(N)];   // the class (kernel, waves per trajectory) that also solves this candidate
+  if (force_nw > 0 && !class_for_waves(N, force_nw, cd)) { set_err("no kernel with that many waves holds this candidate"); return TOPAY_ERR_UNSUPPORTED; }
+  const size_t lds = class_lds_bytes(cd, N);
   if ((s = push_params(c)) != TOPAY_OK) return s;
   HIPCHK(set_kernel_attributes(c->device));
-  hipLaunchKernelGGL(kEvalKernels[bucket_of(N)], dim3(1), dim3(64), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N);
+  if (force_nw > 0) HIPCHK(hipFuncSetAttribute((const void*)cd.eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)class_lds_bytes(cd, cd.max_n)));
+  hipLaunchKernelGGL(cd.eval, dim3(1), dim3(64 * cd.nw), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N, class_compact(cd, N));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   tmp.release();
   if (f) HIPCHK(memcpy_sync(c, f, c->fout.as<double>() + i, 8, hipMemcpyDeviceToHost));
-  if (g) HIPCHK(memcpy_sync(c, g, c->work.as<double>() + (size_t)i * 4 * c->nmax, (size_t)nn * 8, hipMemcpyDeviceToHost));
+  if (g) HIPCHK(memcpy_sync(c, g, c->work.as<double>() + 4 * c->h_noff[i], (size_t)nn * 8, hipMemcpyDeviceToHost));
   if (final_xy_error) HIPCHK(memcpy_sync(c, final_xy_error, c->xyerr.as<double>() + 2 * i, 16, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
@@ -1783,6 +1909,15 @@ extern "C" {
 topay_status topay_eval(topay_ctx* c, int stage, int i, const double* x, const double* alm_lambda, const double* alm_rho,
                         double* f, double* g, double* final_xy_error) {
   return eval_one(c, stage, i, x, alm_lambda, alm_rho, f, g, final_xy_error, false);
+}
+
+// Test hook: the same evaluation by the kernel with `waves` wavefronts per trajectory (1, 2 or 4) instead of the
+// candidate's class default.  An evaluation is order-identical whatever the number of waves (topay_eval_mw.h): the
+// results must agree bit for bit.
+topay_status topay_eval_waves(topay_ctx* c, int stage, int i, int waves, const double* x, const double* alm_lambda, const double* alm_rho,
+                              double* f, double* g, double* final_xy_error) {
+  if (waves != 1 && waves != 2 && waves != 4) return TOPAY_ERR_INVALID_ARG;
+  return eval_one(c, stage, i, x, alm_lambda, alm_rho, f, g, final_xy_error, false, waves);
 }
 
 // The spline of a given decision vector as candidate i's result (MomaTrajOpt keeps the MINCO state of its last cost
@@ -1802,19 +1937,19 @@ topay_status topay_eval_batch(topay_ctx* c, int stage, int repeats, double* f) {
   HIPCHK(hipSetDevice(c->device));
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   // x <- x0 (strided copy), alm <- init
-  std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->B * c->nmax, 0.0), alm((size_t)c->B * 4);
+  std::vector<double> x0((size_t)c->B * (10 * TOPAY_MAX_N - 8)), xs((size_t)c->h_noff[c->B] + 1, 0.0), alm((size_t)c->B * 4);
   HIPCHK(memcpy_sync(c, x0.data(), c->x0.p, x0.size() * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < c->B; b++) {
     if (c->hN[b] == 0) continue;
     const int nn = 10 * c->hN[b] - 8;
-    memcpy(&xs[(size_t)b * c->nmax], &x0[(size_t)b * (10 * TOPAY_MAX_N - 8)], (size_t)nn * 8);
+    memcpy(&xs[(size_t)c->h_noff[b]], &x0[(size_t)b * (10 * TOPAY_MAX_N - 8)], (size_t)nn * 8);
     alm[4 * b] = c->hp.alm_init_lambda[0]; alm[4 * b + 1] = c->hp.alm_init_lambda[1];
     alm[4 * b + 2] = c->hp.alm_init_rho[0]; alm[4 * b + 3] = c->hp.alm_init_rho[1];
   }
-  HIPCHK(memcpy_sync(c, c->x.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->x.p, xs.data(), (size_t)c->h_noff[c->B] * 8, hipMemcpyHostToDevice));
   HIPCHK(memcpy_sync(c, c->alm.p, alm.data(), alm.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipEventRecord(c->ev0, c->stream));
-  topay_status s = launch_classes(c, false, kEvalKernels, stage, repeats);
+  topay_status s = launch_classes<true>(c, false, stage, repeats);
   if (s != TOPAY_OK) return s;
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1834,12 +1969,12 @@ topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, 
   HIPCHK(hipSetDevice(c->device));
   const int B = c->B;
   // scratch is sized from the longest returned trajectory
-  std::vector<double> hT((size_t)B * c->Nmax);
-  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, hT.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> hT((size_t)c->h_poff[B] + 1);
+  HIPCHK(memcpy_sync(c, hT.data(), c->T.p, (size_t)c->h_poff[B] * 8, hipMemcpyDeviceToHost));
   double tmax = 0.0;
   for (int b = 0; b < B; b++) {
     double t = 0.0;
-    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)b * c->Nmax + i];
+    for (int i = 0; i < c->hN[b]; i++) t += hT[(size_t)c->h_poff[b] + i];
     if (t > 0.0 && t < 1.0e4 && t > tmax) tmax = t;
   }
   const long long cap_panels = (long long)(tmax / 0.025) + 4, cap_samples = (long long)(tmax / 0.01) + 16;
@@ -1903,6 +2038,27 @@ topay_status topay_test_math(topay_ctx* c, int n, const double* a, const double*
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(memcpy_sync(c, out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   da.release(); dbb.release(); dout.release();
+  return TOPAY_OK;
+}
+
+// Launch class of a candidate with n_pieces pieces: waves per trajectory and decision-vector elements per thread of
+// the kernel that solves (and, through topay_eval, evaluates) it.  The division of the L-BFGS vectors over the threads
+// -- and with it the rounding of every dot product -- is a function of these two; parity tooling that restates the
+// solver in the device's order needs them (oracle/: device-order mode).
+topay_status topay_class_of(int n_pieces, int* waves, int* elements_per_thread, int* class_index) {
+  if (n_pieces <= 0 || n_pieces > TOPAY_MAX_N) return TOPAY_ERR_TOO_MANY_PIECES;
+  const int k = bucket_of(n_pieces);
+  const ClassDef& cd = class_table()[k];
+  if (waves) *waves = cd.nw;
+  if (elements_per_thread) *elements_per_thread = 2 * cd.rmax;
+  if (class_index) *class_index = k;
+  return TOPAY_OK;
+}
+
+// Device memory held by the resident batch (everything topay_set_init_traj sized), in bytes.
+topay_status topay_workspace_bytes(topay_ctx* c, unsigned long long* bytes) {
+  if (!c || !bytes) return TOPAY_ERR_INVALID_ARG;
+  *bytes = (unsigned long long)c->workspace_bytes;
   return TOPAY_OK;
 }
 

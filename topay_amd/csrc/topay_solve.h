@@ -10,6 +10,7 @@
 // dot products are wave reductions; the whole solve is one launch with a single evaluation call site.
 #pragma once
 #include "topay_eval.h"
+#include "topay_eval_mw.h"
 
 #ifndef TOPAY_PF_ELEMS
 #define TOPAY_PF_ELEMS 24
@@ -45,50 +46,67 @@ struct SolveIO {
 typedef double dpair __attribute__((vector_size(16)));   // plain vector type: loads through address-space pointers need no constructor
 typedef const TOPAY_GLB dpair* glb_cpp;
 typedef TOPAY_GLB dpair* glb_pp;
-__device__ __forceinline__ bool vec_in(int lane, int t, int n) { return 128 * (t >> 1) + 2 * lane < n; }
-template <int EPL>
-__device__ __forceinline__ void vec_load(glb_cdp a, int n, int lane, double (&v)[EPL]) {
+// (NT = threads per trajectory: 64 for the one-wave kernels; an NW-wave workgroup divides the pairs over 64 NW threads,
+// thread tid owning the pairs NT p + tid)
+template <int NT = 64>
+__device__ __forceinline__ bool vec_in(int tid, int t, int n) { return 2 * (NT * (t >> 1) + tid) < n; }
+template <int EPL, int NT = 64>
+__device__ __forceinline__ void vec_load(glb_cdp a, int n, int tid, double (&v)[EPL]) {
   static_assert(EPL % 2 == 0, "pairs");
   const glb_cpp ap = (glb_cpp)a;
   const int last = (n >> 1) - 1;
 #pragma unroll
   for (int p = 0; p < EPL / 2; p++) {
-    const int i = 64 * p + lane;
+    const int i = NT * p + tid;
     const dpair q = ap[i <= last ? i : last];
     v[2 * p] = q[0];
     v[2 * p + 1] = q[1];
   }
 }
-template <int EPL>
-__device__ __forceinline__ void vec_store(glb_dp a, int n, int lane, const double (&v)[EPL]) {
+template <int EPL, int NT = 64>
+__device__ __forceinline__ void vec_store(glb_dp a, int n, int tid, const double (&v)[EPL]) {
   const glb_pp ap = (glb_pp)a;
 #pragma unroll
   for (int p = 0; p < EPL / 2; p++) {
-    const int i = 64 * p + lane;
+    const int i = NT * p + tid;
     dpair q;
     q[0] = v[2 * p];
     q[1] = v[2 * p + 1];
     if (2 * i < n) ap[i] = q;
   }
 }
-// sum over the lane's elements in ascending t, then the fixed wave tree (same order as a plain strided loop)
-template <int EPL>
-__device__ __forceinline__ double vec_dot(glb_cdp a, glb_cdp b, int n, int lane) {
+// a thread's share of sum a[e] b[e]: its elements in ascending t (the caller finishes with the fixed wave / workgroup tree)
+template <int EPL, int NT = 64>
+__device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int tid) {
   double av[EPL], bv[EPL];
-  vec_load<EPL>(a, n, lane, av);
-  vec_load<EPL>(b, n, lane, bv);
+  vec_load<EPL, NT>(a, n, tid, av);
+  vec_load<EPL, NT>(b, n, tid, bv);
   double s = 0.0;
 #pragma unroll
-  for (int t = 0; t < EPL; t++) s += vec_in(lane, t, n) ? av[t] * bv[t] : 0.0;
-  return wave_sum(s);
+  for (int t = 0; t < EPL; t++) s += vec_in<NT>(tid, t, n) ? av[t] * bv[t] : 0.0;
+  return s;
 }
 
-template <int RMAX>
+template <int RMAX, int NW = 1>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
                                                  lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out) {
   const DevParams& P = g_P;
-  const int lane = C.lane, n = __builtin_amdgcn_readfirstlane(C.n);
-  constexpr int EPL = 2 * RMAX;  // decision-vector elements per lane: n <= 64 * EPL
+  constexpr int NT = 64 * NW;    // threads of this trajectory's workgroup
+  const int tid = C.tid, n = __builtin_amdgcn_readfirstlane(C.n);
+  constexpr int EPL = 2 * RMAX;  // decision-vector elements per thread: n <= NT * EPL
+  // sums / maxima over the trajectory's threads in a fixed order: the wave tree, then (NW > 1) the waves' partial results
+  // through LDS, (w0 + w1) + (w2 + w3)
+  const int wave = __builtin_amdgcn_readfirstlane(C.wave);
+  const lds_dp c_red = C.red;
+  int rp = 0;
+  auto wsum = [&](double v) -> double {
+    if constexpr (NW == 1) return wave_sum(v);
+    else return wg_sum<NW>(c_red, rp, wave, v);
+  };
+  auto wmax = [&](double v) -> double {
+    if constexpr (NW == 1) return wave_max(v);
+    else return wg_max<NW>(c_red, rp, wave, v);
+  };
   int stage = 1;
   int alm_iter = 0;
   bool success = false;
@@ -149,8 +167,15 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       qk[6] = (unsigned long long)S.hist_y; qk[7] = (unsigned long long)S.hist_ys; qk[8] = (unsigned long long)S.hist_al;
       qk[9] = (unsigned long long)S.stats; qk[10] = (unsigned long long)S.trace; qk[11] = (unsigned long long)mp;
     }
-    if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
-    else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+    if constexpr (NW == 1) {
+      if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
+      else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+    } else {
+      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW>(C, mp, gate);
+      else f = eval_cost_grad_mw<2, RMAX, NW>(C, mp, gate);
+      wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
+      rp = 0;
+    }
     {
       // (read back as wave-uniform values: scalar registers, scalar branches, scalar base addresses for the vector loads)
       lds_cdp pk = pf + 8;
@@ -179,7 +204,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     }
     evals++;
 #ifndef TOPAY_STAMPS
-    if (S.trace && lane == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;
+    if (S.trace && tid == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;
 #endif
     ntrace++;
 
@@ -188,29 +213,29 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     if (mode == MODE_INIT) {
       // lbfgs.hpp:523-554
       fx = f;
-      if (lane == 0) pf[0] = fx;
+      if (tid == 0) pf[0] = fx;
       double gmax = 0.0, xmax = 0.0;
       {
         double gv[EPL], xv[EPL], dv[EPL];
-        vec_load<EPL>(S.g, n, lane, gv);
-        vec_load<EPL>(S.x, n, lane, xv);
+        vec_load<EPL, NT>(S.g, n, tid, gv);
+        vec_load<EPL, NT>(S.x, n, tid, xv);
 #pragma unroll
         for (int t = 0; t < EPL; t++) {
-          const bool in = vec_in(lane, t, n);
+          const bool in = vec_in<NT>(tid, t, n);
           dv[t] = -gv[t];
           gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
           xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
         }
-        vec_store<EPL>(S.d, n, lane, dv);
+        vec_store<EPL, NT>(S.d, n, tid, dv);
       }
-      gmax = wave_max(gmax);
-      xmax = wave_max(xmax);
+      gmax = wmax(gmax);
+      xmax = wmax(xmax);
       k = 0;
       if (gmax / fmax(1.0, xmax) < lp.g_epsilon) {
         ret = TOPAY_LBFGS_CONVERGENCE;
         go = GO_RUN_END;
       } else {
-        step = 1.0 / sqrt(vec_dot<EPL>(S.d, S.d, n, lane));
+        step = 1.0 / sqrt(wsum(vec_dot_part<EPL, NT>(S.d, S.d, n, tid)));
         k = 1;
         end = 0;
         bound = 0;
@@ -230,7 +255,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           nu = stp;
           brackt = true;
         } else {
-          const double gs = vec_dot<EPL>(S.g, S.d, n, lane);
+          const double gs = wsum(vec_dot_part<EPL, NT>(S.g, S.d, n, tid));
           if (gs < dstest) mu = stp;
           else accepted = true;
         }
@@ -250,11 +275,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       if (ls == 0) {
         {
           double pv[EPL], dv[EPL], xv[EPL];
-          vec_load<EPL>(S.xp, n, lane, pv);
-          vec_load<EPL>(S.d, n, lane, dv);
+          vec_load<EPL, NT>(S.xp, n, tid, pv);
+          vec_load<EPL, NT>(S.d, n, tid, dv);
 #pragma unroll
           for (int t = 0; t < EPL; t++) xv[t] = pv[t] + stp * dv[t];
-          vec_store<EPL>(S.x, n, lane, xv);
+          vec_store<EPL, NT>(S.x, n, tid, xv);
         }
         go = GO_EVAL;
       } else if (ls < 0) {
@@ -262,10 +287,10 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         fx = f;
         {
           double pv[EPL], qv[EPL];
-          vec_load<EPL>(S.xp, n, lane, pv);
-          vec_load<EPL>(S.gp, n, lane, qv);
-          vec_store<EPL>(S.x, n, lane, pv);
-          vec_store<EPL>(S.g, n, lane, qv);
+          vec_load<EPL, NT>(S.xp, n, tid, pv);
+          vec_load<EPL, NT>(S.gp, n, tid, qv);
+          vec_store<EPL, NT>(S.x, n, tid, pv);
+          vec_store<EPL, NT>(S.g, n, tid, qv);
         }
         ret = ls;
         go = GO_RUN_END;
@@ -280,17 +305,17 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           double gmax = 0.0, xmax = 0.0;
           {
             double gv[EPL], xv[EPL];
-            vec_load<EPL>(S.g, n, lane, gv);
-            vec_load<EPL>(S.x, n, lane, xv);
+            vec_load<EPL, NT>(S.g, n, tid, gv);
+            vec_load<EPL, NT>(S.x, n, tid, xv);
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-              const bool in = vec_in(lane, t, n);
+              const bool in = vec_in<NT>(tid, t, n);
               gmax = in ? fmax(gmax, fabs(gv[t])) : gmax;
               xmax = in ? fmax(xmax, fabs(xv[t])) : xmax;
             }
           }
-          gmax = wave_max(gmax);
-          xmax = wave_max(xmax);
+          gmax = wmax(gmax);
+          xmax = wmax(xmax);
           if (gmax / fmax(1.0, xmax) < lp.g_epsilon) { ret = TOPAY_LBFGS_CONVERGENCE; fin = true; }
         }
         if (!fin && past > 0) {
@@ -300,7 +325,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           }
           if (!fin) {
             __syncthreads();
-            if (lane == 0) pf[k % past] = fx;
+            if (tid == 0) pf[k % past] = fx;
             __syncthreads();
           }
         }
@@ -315,24 +340,24 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
           double ys = 0.0, yy = 0.0, ss = 0.0, gg = 0.0;
           {
             double xv[EPL], pv[EPL], gv[EPL], qv[EPL], sv[EPL], yv[EPL], dv[EPL];
-            vec_load<EPL>(S.x, n, lane, xv);
-            vec_load<EPL>(S.xp, n, lane, pv);
-            vec_load<EPL>(S.g, n, lane, gv);
-            vec_load<EPL>(S.gp, n, lane, qv);
+            vec_load<EPL, NT>(S.x, n, tid, xv);
+            vec_load<EPL, NT>(S.xp, n, tid, pv);
+            vec_load<EPL, NT>(S.g, n, tid, gv);
+            vec_load<EPL, NT>(S.gp, n, tid, qv);
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-              const bool in = vec_in(lane, t, n);
+              const bool in = vec_in<NT>(tid, t, n);
               const double se = xv[t] - pv[t], ye = gv[t] - qv[t], gpe = qv[t];
               sv[t] = se;
               yv[t] = ye;
               ys += in ? ye * se : 0.0; yy += in ? ye * ye : 0.0; ss += in ? se * se : 0.0; gg += in ? gpe * gpe : 0.0;
               dv[t] = -gv[t];
             }
-            vec_store<EPL>(sE, n, lane, sv);
-            vec_store<EPL>(yE, n, lane, yv);
-            vec_store<EPL>(S.d, n, lane, dv);
+            vec_store<EPL, NT>(sE, n, tid, sv);
+            vec_store<EPL, NT>(yE, n, tid, yv);
+            vec_store<EPL, NT>(S.d, n, tid, dv);
           }
-          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gg = wave_sum(gg);
+          ys = wsum(ys); yy = wsum(yy); ss = wsum(ss); gg = wsum(gg);
           // 1/ys is stored instead of ys: one division per iteration instead of two per history pair.
           // Every lane stores the same value; each lane later reads back its own store.
           S.hist_ys[end] = 1.0 / ys;
@@ -354,9 +379,9 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             double dr[EPL];
             {
               double gv[EPL];
-              vec_load<EPL>(S.g, n, lane, gv);
+              vec_load<EPL, NT>(S.g, n, tid, gv);
 #pragma unroll
-              for (int t = 0; t < EPL; t++) dr[t] = vec_in(lane, t, n) ? -gv[t] : 0.0;
+              for (int t = 0; t < EPL; t++) dr[t] = vec_in<NT>(tid, t, n) ? -gv[t] : 0.0;
             }
             double sb[PF][EPL], yb[PF][EPL], rb[PF];
             // [mem <= 256]: every lane writes / reads the same entry (LDS broadcast).  The ring lives in the evaluation's
@@ -373,7 +398,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
               const int last = (n >> 1) - 1;
 #pragma unroll
               for (int p = 0; p < EPL / 2; p++) {
-                const int i = 64 * p + lane;
+                const int i = NT * p + tid;
                 const bool in = i <= last;
                 const dpair sv = sj[in ? i : last], yv = yj[in ? i : last];
                 sb[slot][2 * p] = in ? sv[0] : 0.0;
@@ -398,7 +423,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                   double part = 0.0;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
-                  const double al = wave_sum(part) * rb[u];
+                  const double al = wsum(part) * rb[u];
                   alpha[j] = al;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
@@ -428,7 +453,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                   double part = 0.0;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
-                  const double beta = wave_sum(part) * rb[u];
+                  const double beta = wsum(part) * rb[u];
                   const double co = av - beta;
 #pragma unroll
                   for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
@@ -437,7 +462,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                 jl = jl + 1 == memu ? 0 : jl + 1;
               }
             }
-            vec_store<EPL>(S.d, n, lane, dr);
+            vec_store<EPL, NT>(S.d, n, tid, dr);
             SUBSTAMP_END(C, 10);  // two-loop recursion
           }
           step = 1.0;
@@ -450,10 +475,10 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       // lbfgs.hpp:559-573 + line-search prologue 288-311
       {
         double xv[EPL], gv[EPL];
-        vec_load<EPL>(S.x, n, lane, xv);
-        vec_load<EPL>(S.g, n, lane, gv);
-        vec_store<EPL>(S.xp, n, lane, xv);
-        vec_store<EPL>(S.gp, n, lane, gv);
+        vec_load<EPL, NT>(S.x, n, tid, xv);
+        vec_load<EPL, NT>(S.g, n, tid, gv);
+        vec_store<EPL, NT>(S.xp, n, tid, xv);
+        vec_store<EPL, NT>(S.gp, n, tid, gv);
       }
       stp = step;
       count = 0;
@@ -464,7 +489,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       int err = 0;
       if (!(stp > 0.0)) err = TOPAY_LBFGSERR_INVALIDPARAMETERS;
       else {
-        dginit = vec_dot<EPL>(S.gp, S.d, n, lane);
+        dginit = wsum(vec_dot_part<EPL, NT>(S.gp, S.d, n, tid));
         if (0.0 < dginit) err = TOPAY_LBFGSERR_INCREASEGRADIENT;
       }
       if (err) {
@@ -476,11 +501,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
         dstest = lp.s_curv_coeff * dginit;
         {
           double pv[EPL], dv[EPL], xv[EPL];
-          vec_load<EPL>(S.xp, n, lane, pv);
-          vec_load<EPL>(S.d, n, lane, dv);
+          vec_load<EPL, NT>(S.xp, n, tid, pv);
+          vec_load<EPL, NT>(S.d, n, tid, dv);
 #pragma unroll
           for (int t = 0; t < EPL; t++) xv[t] = pv[t] + stp * dv[t];
-          vec_store<EPL>(S.x, n, lane, xv);
+          vec_store<EPL, NT>(S.x, n, tid, xv);
         }
         mode = MODE_LS;
         go = GO_EVAL;
@@ -514,7 +539,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       mode = MODE_INIT;
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     S.stats[0] = st_s1_ret; S.stats[1] = st_s1_it; S.stats[2] = st_s1_ev; S.stats[3] = st_s2_ret;
     S.stats[4] = st_s2_it; S.stats[5] = st_s2_ev; S.stats[6] = alm_iter; S.stats[7] = st_sumb;
   }

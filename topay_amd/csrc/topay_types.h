@@ -6,12 +6,14 @@
 #define TOPAY_SP 25         // samples per piece = 2K+1
 #define TOPAY_EP 13         // even ("full") samples per piece = K+1
 #define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
-// Pieces per trajectory this build solves: 6N <= 384 system rows = 6 rows per lane, one piece per lane (N <= 64 = a 96 s
-// trajectory at the reference's 1.5 s sample_interval).  Launch classes by rows per lane: N <= 10 one row, <= 21 two,
-// <= 32 three, <= 42 four, <= 64 six.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer candidates are
-// reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them as n_not_launched).
-#define TOPAY_MAX_N 64
-#define TOPAY_NBUCKET 6
+// Pieces per trajectory this build solves: 128 (a 192 s trajectory at the reference's 1.5 s sample_interval), the
+// most a four-wave workgroup holds in the 160 KB of LDS of a compute unit (compact layout, topay_eval_mw.h).  Launch
+// classes: N <= 10 / 15 / 21 / 32 one wave per trajectory (1 / 2 / 2 / 3 system rows per lane), N <= 42 / 64 one wave
+// (4 / 6 rows per lane) or several, N <= 128 four waves.  The reference itself has no cap (moma_traj_opt.cpp:245,
+// 300-321); longer candidates are reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them
+// as n_not_launched).
+#define TOPAY_MAX_N 128
+#define TOPAY_NBUCKET 7
 #define TOPAY_WAVE 64
 
 // Address-space qualified pointers.  LDS and HBM pointers travel through structs and (non-inlined) device
@@ -79,9 +81,14 @@ struct DevParams {
   double relT[3];
 };
 
-// Per-batch device arrays (structure of arrays; strides Nmax / nmax fixed per batch).
+// Per-batch device arrays.  Fixed-size blocks are indexed by the candidate; the variable-length ones (everything sized
+// by the candidate's pieces N or its decision vector n = 10 N - 8) are packed by the candidate's own size, at the
+// offsets poff[b] = pieces of the candidates before b and noff[b] = decision-vector elements before b -- not strided by
+// the longest member of the batch (one 64-piece candidate among 8192 would otherwise double the history of all).
 struct DevBatch {
-  int B, Nmax, nmax, hist_m;
+  int B, hist_m;
+  const long long* poff;  // [B + 1]
+  const long long* noff;  // [B + 1]
   // inputs produced by the init kernel
   int* N;             // [B] pieces
   int* s1_past;       // [B]
@@ -90,27 +97,27 @@ struct DevBatch {
   double* tail;       // [B][27]
   double* start_xy;   // [B][2]
   double* goal_xy;    // [B][2]
-  double* init_xy;    // [B][Nmax][2]
-  double* x0;         // [B][nmax]  packed initial decision vector
+  double* init_xy;    // [B][TOPAY_MAX_N][2]
+  double* x0;         // [B][10 TOPAY_MAX_N - 8]  packed initial decision vector (written before N is known)
   // solver state
-  double* x;          // [B][nmax]
-  double* work;       // [B][4][nmax]  g, xp, gp, d
-  double* hist_s;     // [B][m][nmax]
-  double* hist_y;     // [B][m][nmax]
+  double* x;          // [noff]  n per candidate
+  double* work;       // [4 noff]  g, xp, gp, d (n each) per candidate
+  double* hist_s;     // [m noff]  [m][n] per candidate
+  double* hist_y;     // [m noff]
   double* hist_ys;    // [B][m]
   double* hist_alpha; // [B][m]
-  double* lu;         // [B][14*6*Nmax]  LU stash (band + reciprocal diagonal)
+  double* lu;         // [84 poff]  LU stash (band + reciprocal diagonal), 14 x 6N per candidate
   // outputs
   int* success;       // [B]
   double* cost;       // [B]
   int* stats;         // [B][8]
   double* xyerr;      // [B][2]
-  double* coef;       // [B][9*6*Nmax]  (6N x 9 col-major, stride 6N of the trajectory)
-  double* T;          // [B][Nmax]
-  double* knots;      // [B][(Nmax+1)*2]
+  double* coef;       // [54 poff]  6N x 9 col-major per candidate
+  double* T;          // [poff]
+  double* knots;      // [2 (poff + b)]  N + 1 knots per candidate
   double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
   double* fout;       // [B] eval hook output
-  double* sbuf;       // [B][14][13*Nmax] per-sample gradient rows parked between the cost and the gradient phase
+  double* sbuf;       // [182 poff]  [14][13 N] per-sample gradient rows parked between the cost and the gradient phase
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
   // persistent launches: one queue per N-class = positions [queue_off[k], queue_off[k] + queue_count[k]) of `order`, handed
   // out through the device counters queue_next[k]; a workgroup of class queue_class drains its own queue, then the
