@@ -164,3 +164,20 @@ planner_node:
         assert bytes(q) == bytes(d)
         assert sorted(ign) == ["first_stage/mean_time_weight", "mean_time_lowb", "mean_time_uppb", "second_stage/alm_data/epsilon_con",
                                "second_stage/alm_data/max_iter"]
+
+
+def test_isa_lint_recognises_the_defect_pattern(tmp_path):
+    """tools/isa_lint.py (run by build() on the product sources): a join block with a lane-wise copy ahead of its EXEC
+    restore is reported, the regular shape is not."""
+    import subprocess
+    import sys
+
+    bad = tmp_path / "bad.s"
+    bad.write_text("k_x:\n\ts_and_saveexec_b64 s[4:5], vcc\n\ts_cbranch_execz .LBB0_2\n\tv_add_f64 v[0:1], v[0:1], v[2:3]\n.LBB0_2:\n"
+                   "\tv_readlane_b32 s0, v255, 4\n\tv_accvgpr_write_b32 a86, v152\n\ts_or_b64 exec, exec, s[4:5]\n\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text("k_x:\n\ts_and_saveexec_b64 s[4:5], vcc\n\ts_cbranch_execz .LBB0_2\n\tv_add_f64 v[0:1], v[0:1], v[2:3]\n.LBB0_2:\n"
+                    "\tv_readlane_b32 s0, v255, 4\n\ts_or_b64 exec, exec, s[4:5]\n\tv_accvgpr_write_b32 a86, v152\n\ts_endpgm\n")
+    tool = os.path.join(ROOT, "tools", "isa_lint.py")
+    assert subprocess.run([sys.executable, tool, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([sys.executable, tool, str(good)], capture_output=True).returncode == 0

@@ -1232,10 +1232,21 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
 #ifdef TOPAY_STAMPS
 #endif
     SUBSTAMP_BEGIN(C);
-    if (act && !skip_body) {
+    if (!skip_body) {
+      // Wave-uniform condition on purpose: the sample body calls the non-inlined manipulator block, and a call under a
+      // partial EXEC mask is where this kernel family has failed on hardware only (wrong lanes passing `lane == 0`
+      // after the call: state the caller keeps in VGPR lanes / scratch across a divergent call).
+      // Lanes beyond the last sample evaluate the first sample of the last piece and their results are dropped.
       double cst;
       sample_body<STAGE>(C, cL, rows, i, j, step, half, posx, posy, pbuf + lane, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
-      cost_pen += cst;
+      if (act) {
+        cost_pen += cst;
+      } else {
+#pragma unroll
+        for (int v = 0; v < 12; v++) gB[v] = 0.0;
+        gdTs = 0.0; gpx = 0.0; gpy = 0.0;
+        jva = false;
+      }
     }
     SUBSTAMP_END(C, 12);  // sample body of lane 0
     if (act && !skip_body) {

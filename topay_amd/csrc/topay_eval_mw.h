@@ -352,10 +352,12 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       for (int v = 0; v < 12; v++) gB[v] = 0.0;
       double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
       bool jva = false;
-      if (act && !skip_body) {
+      if (!skip_body) {   // (wave-uniform: no call of the non-inlined manipulator block under a partial EXEC mask, see topay_eval.h)
         double cst;
         sample_body<STAGE>(C, cL, rows, i, j, step, half, posx, posy, pbuf + lane, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
-        cst_out = cst;
+        if (act) cst_out = cst;
+      }
+      if (act && !skip_body) {
         gxy[2 * e] = gpx;
         gxy[2 * e + 1] = gpy;
         glb_dp sb = C.sbuf + e;

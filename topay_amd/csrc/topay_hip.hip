@@ -470,13 +470,17 @@ static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
         {10, 1, 1, k_solve1, k_eval1}, {15, 2, 1, k_solve2, k_eval2}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
-        {42, 2, 4, k_solve2w4, k_eval2w4}, {64, 2, 4, k_solve2w4, k_eval2w4}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
+        {42, 2, 2, k_solve2w2, k_eval2w2}, {64, 3, 2, k_solve3w2, k_eval3w2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
+    // Two waves for N = 33..64 by default: measured on one box with three batches in flight (tools/r3_mw_ab.sh), one /
+    // two / four waves for both classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 /
+    // 1.03 s.  Four waves halve a long candidate's solve but occupy four SIMD slots for it (the serial parts -- LU,
+    // substitutions -- leave three of them idle), two waves fill the SIMD the candidate's LDS would idle anyway.
     auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    const int w4 = env_nw("TOPAY_MW_C4", 4), w5 = env_nw("TOPAY_MW_C5", 4);
+    const int w4 = env_nw("TOPAY_MW_C4", 2), w5 = env_nw("TOPAY_MW_C5", 2);
     if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4};
-    else if (w4 == 2) t[4] = {42, 2, 2, k_solve2w2, k_eval2w2};
+    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4};
     if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6};
-    else if (w5 == 2) t[5] = {64, 3, 2, k_solve3w2, k_eval3w2};
+    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4};
     return t;
   }();
   return tab;
