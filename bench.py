@@ -5,7 +5,8 @@ Workload ("benchmark_tables batch"): S independent 'tables' scenarios per GPU, e
 (the reference's benchmark loop regenerates the map every episode, src/planner/src/planner.cpp:514-521) and 8 topological
 candidate init paths (the reference's cap, planner.cpp:59,829).  One step = the whole hot path over the batch with the
 maps resident in HBM: upload of the raw init paths + the init kernel (optimizeTraj lines 146-357) + the persistent solve
-kernels (lines 359-497: stage-1 L-BFGS, stage-2 ALM loop) + the feasibility gate (planner.cpp:878-880) + download of
+kernels (lines 359-497: stage-1 L-BFGS, stage-2 ALM loop; the solving wave also applies the feasibility gate of
+planner.cpp:878-880 to its result) + download of
 flags, costs and durations, the per-scenario winner selection (planner.cpp:999-1016) and download of the winners'
 trajectories + the gather of per-scenario result records (RCCL all-gather when N > 1).  Three batches are kept in
 flight by default (--inflight); the strictly serial figures are measured in the same run and reported beside the line.
@@ -75,6 +76,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial", action="store_true", help="skip the strictly serial steps measured beside a pipelined run")
+    ap.add_argument("--no-planner", action="store_true",
+                    help="skip the planner-semantics figure (the same steps with the reference's cancellation of a planning call's "
+                         "remaining candidates 100 ms after its first accepted one, planner.cpp:943-952), measured beside the line")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] latency figure (profiling runs)")
     ap.add_argument("--workload", choices=["tables", "hires"], default="tables",
                     help="tables: the headline benchmark_tables batch; hires: BASELINE config 5, ONE cuboids map at 0.02 m "
@@ -167,10 +171,14 @@ def main():
     scen_global = tb.scen.astype(np.int64) + rank * S
     scen_ids = np.array(sorted(set(scen_global.tolist())), dtype=np.int64)
 
+    cancel_budget = [0]                  # > 0: the planner's cancellation window, in piece-evaluations (2400 = 100 ms)
+
     def issue(o_):
         # optimizeTraj:146-357: host-to-device copy of the raw init paths + the init kernel, then the persistent solve
         # kernels (optimizeTraj:359-497).  The maps stay resident (the reference builds its map before optimizeTraj).
         o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids_of[id(o_)])
+        if cancel_budget[0] > 0:
+            o_.set_groups(tb.scen, cancel_budget[0])
         o_.optimize_async()
 
     gathers = []
@@ -256,6 +264,28 @@ def main():
         rs = run(ns, 1)
         torch.cuda.synchronize()
         serial = {"steps": ns, "ms_per_step": (time.perf_counter() - ts) / ns * 1e3, "kernel_ms": float(np.mean([r[1] for r in rs]))}
+    # The same steps as the planner runs them: the candidates of a planning call still running 100 ms (2400
+    # piece-evaluations) after the call's first accepted candidate are interrupted and count as failed.  Outside the timed
+    # region and beside the line: `value` is the full figure, every candidate solved to its own end.
+    planner = None
+    if not args.no_planner and not hires:
+        np_ = max(depth, min(6, args.steps))
+        cancel_budget[0] = 2400
+        run(depth)                        # (fill the pipeline with cancelling batches first)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        rp_ = run(np_)
+        torch.cuda.synchronize()
+        tpe = time.perf_counter() - tp
+        cancel_budget[0] = 0
+        o_last = opts[(np_ - 1) % depth]
+        intr = o_last.interrupted()
+        acc_ = rp_[-1][0] & o_last.check_feasible()
+        solved_scen = len(set(tb.scen[acc_].tolist()))
+        planner = {"steps": np_, "ms_per_step": tpe / np_ * 1e3,
+                   "trajectories_per_s_per_gpu": (B - n_not_launched) / (tpe / np_),
+                   "cancel_window": "2400 piece-evaluations after a scenario's first accepted candidate (= the reference's 100 ms at 42 us per piece-evaluation)",
+                   "interrupted_fraction": float(intr.mean()), "scenarios_with_a_trajectory": int(solved_scen)}
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -344,9 +374,9 @@ def main():
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
             "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),
             "p99_evals_per_traj": float(np.percentile(stats[:, 2] + stats[:, 5], 99)),
-            "timed_region": "per step: host-to-device copy of the raw init paths + init kernel + persistent solve kernels + "
-                            "feasibility gate kernel + device-to-host copy of flags, costs, durations and of the per-scenario "
-                            "winners' trajectories (+ the RCCL record gather when N > 1); maps resident",
+            "timed_region": "per step: host-to-device copy of the raw init paths + init kernel + persistent solve kernels (the "
+                            "solving wave also runs the feasibility gate on its result) + device-to-host copy of flags, costs, "
+                            "durations and of the per-scenario winners' trajectories (+ the RCCL record gather when N > 1); maps resident",
             "h2d_bytes_per_step": int(tb.paths.nbytes + tb.lens.nbytes + 4 * B),
             "winners_per_step": int(winners.get("n", 0)),
             "d2h_winner_bytes_per_step": int(sum(v.nbytes for v in winners["last"].values())) if "last" in winners else 0,
@@ -355,6 +385,8 @@ def main():
             "setup_seconds_untimed": setup_s,
             "esdf_build_ms_gpu_untimed": edt_ms,
             "config1_latency": cfg1,
+            "planner_semantics": planner,
+            "workspace_bytes_per_context": int(opt.workspace_bytes()), "contexts": depth,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

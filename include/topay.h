@@ -355,6 +355,25 @@ topay_status topay_get_trace(topay_ctx* ctx, int i, double* out);
  * out[4i..] = sin(a_i), cos(a_i), atan2(a_i, b_i), sqrt(|a_i|)/(1+|b_i|). */
 topay_status topay_test_math(topay_ctx* ctx, int n, const double* a, const double* b, double* out4n);
 
+/* == the planner's thread group and its cancellation (planner.cpp:829-952): the candidates of one planning call run
+ * concurrently, and 100 ms after the first of them has succeeded (optimizeTraj true AND printConstraintsSituations
+ * passed) the ones still running are interrupted (threads.interrupt_all(); interruption points: top of the ALM loop and
+ * every second-stage cost evaluation, moma_traj_opt.cpp:402, 887) and count as failed.
+ *   group_id[b]    planning call of candidate b, -1 = none (NULL: no groups)
+ *   cancel_budget  the 100 ms in the deterministic unit of alm_work_budget: piece-evaluations (stage-1 + stage-2
+ *                  evaluations x pieces; 24 000 = 1 s, so 2400 = 100 ms); 0 = no cancellation (the default)
+ * The rule is applied on the candidates' own work clocks -- a candidate counts iff its clock at the end is within
+ * cancel_budget of the smallest clock of a feasible success of its call -- so the outcome does not depend on how the
+ * device happened to schedule the candidates; the solve stops a candidate as soon as it can see that it is past the limit.
+ * Interrupted candidates: success 0, stage-2 status TOPAY_INTERRUPTED, topay_get_interrupted 1.
+ * Call after topay_set_init_traj (a new batch starts without groups). */
+#define TOPAY_INTERRUPTED (-2000)
+topay_status topay_set_groups(topay_ctx* ctx, const int* group_id /* batch */, int cancel_budget);
+/* threads.interrupt_all() (planner.cpp:952) for the solve in flight: every candidate stops at its next interruption
+ * point.  Returns at once (callable from another thread than the one in topay_synchronize). */
+topay_status topay_cancel(topay_ctx* ctx);
+topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */);
+
 /* Launch class of a candidate with n_pieces pieces: waves per trajectory (1, 2 or 4) and decision-vector elements per
  * thread of the kernel that solves and (topay_eval) evaluates it.  For parity tooling: the rounding of the solver's dot
  * products depends on how the vectors are divided over the threads.  Any output pointer may be NULL. */

@@ -295,3 +295,14 @@ def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1, gate=False):
     if gate:   # total duration and printConstraintsSituations verdict of every returned trajectory
         out.update(total_duration=dur, gate=gt)
     return out
+
+
+def group_cancel(group_id, clock, accepted, budget=2400):
+    """The planner's cancellation rule (planner.cpp:829-952) on work clocks: bool array, True = interrupted."""
+    L = lib()
+    g = np.ascontiguousarray(group_id, dtype=np.int32)
+    c = np.ascontiguousarray(clock, dtype=np.int64)
+    a = np.ascontiguousarray(accepted, dtype=np.int32)
+    out = np.zeros(len(g), dtype=np.int32)
+    L.orc_group_cancel(len(g), _ip(g), c.ctypes.data_as(C.POINTER(C.c_longlong)), _ip(a), C.c_longlong(int(budget)), _ip(out))
+    return out.astype(bool)

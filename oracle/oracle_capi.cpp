@@ -3,6 +3,7 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <limits>
 #include <thread>
 
 #include "topay_oracle.hpp"
@@ -297,6 +298,26 @@ double orc_optimize_batch_maps(int n_maps, const double* origin /*[M][3]*/, cons
   for (int t = 0; t < std::max(1, nthreads); t++) th.emplace_back(worker);
   for (auto& t : th) t.join();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// The planner's cancellation of a planning call's thread group (planner.cpp:829-952) on the deterministic work clock:
+// threads start together, every candidate advances one piece-evaluation per unit of time; `tau` of a call = the clock at
+// which its first candidate finished with optimizeTraj true AND the gate passed (future_succ), and whoever is still
+// running `budget` units later (the 100 ms of cv_all.wait_for) is interrupted at its next interruption point
+// (moma_traj_opt.cpp:402, 887) and has no result.  clock[b] = (stage-1 + stage-2 evaluations) x pieces of candidate b run
+// to its own end; accepted[b] = success && gate.  Writes interrupted[b]; returns the number of interrupted candidates.
+int orc_group_cancel(int batch, const int* group_id, const long long* clock, const int* accepted, long long budget, int* interrupted) {
+  int ng = 0;
+  for (int b = 0; b < batch; b++) ng = std::max(ng, group_id[b] + 1);
+  std::vector<long long> tau(ng, std::numeric_limits<long long>::max() / 4);
+  for (int b = 0; b < batch; b++)
+    if (group_id[b] >= 0 && accepted[b]) tau[group_id[b]] = std::min(tau[group_id[b]], clock[b]);
+  int n = 0;
+  for (int b = 0; b < batch; b++) {
+    interrupted[b] = (group_id[b] >= 0 && clock[b] > tau[group_id[b]] + budget) ? 1 : 0;
+    n += interrupted[b];
+  }
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------

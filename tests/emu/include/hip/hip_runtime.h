@@ -234,6 +234,7 @@ inline unsigned long long __ballot(int pred) {
 inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }  // lanes are fibers of one thread
 inline int atomicOr(int* p, int v) { int o = *p; *p |= v; return o; }
+inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 inline int __all(int pred) {
   int lanes = (int)(hip_emu::S().bdim.x);
   unsigned long long full = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1);

@@ -122,6 +122,9 @@ def load(path=None):
     L.topay_load_solution.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
     L.topay_gate_timeouts.argtypes = [C.c_void_p, c_ip]
     L.topay_class_of.argtypes = [C.c_int, c_ip, c_ip, c_ip]
+    L.topay_set_groups.argtypes = [C.c_void_p, c_ip, C.c_int]
+    L.topay_cancel.argtypes = [C.c_void_p]
+    L.topay_get_interrupted.argtypes = [C.c_void_p, c_ip]
     L.topay_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.topay_eval_waves.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.topay_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp]
@@ -555,6 +558,20 @@ class MomaTrajOptBatch:
         b = C.c_ulonglong(0)
         _chk(self.L, self.L.topay_workspace_bytes(self.h, C.byref(b)))
         return int(b.value)
+
+    def set_groups(self, group_id, cancel_budget=2400):
+        """Planning call (scenario) of every candidate and the cancellation window after a call's first feasible success, in
+        piece-evaluations (2400 = the reference's 100 ms); None / 0 switches cancellation off."""
+        g = None if group_id is None else np.ascontiguousarray(group_id, dtype=np.int32)
+        _chk(self.L, self.L.topay_set_groups(self.h, _ip(g), int(cancel_budget) if g is not None else 0))
+
+    def cancel(self):
+        _chk(self.L, self.L.topay_cancel(self.h))
+
+    def interrupted(self):
+        out = np.zeros(self.batch, dtype=np.int32)
+        _chk(self.L, self.L.topay_get_interrupted(self.h, _ip(out)))
+        return out.astype(bool)
 
     def gate_timeouts(self):
         n = C.c_int(0)

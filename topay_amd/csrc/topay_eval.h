@@ -92,6 +92,17 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
+// Hand-off through GLOBAL memory between the lanes of one wave (stores by some lanes, loads by others): the stores are
+// complete (vmcnt) before any lane goes on, without a workgroup barrier -- usable by one wave of a several-waves workgroup.
+__device__ __forceinline__ void wave_global_sync() {
+#ifndef TOPAY_CPU_EMU
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
 // inclusive prefix sum over lanes
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 #pragma unroll

@@ -35,13 +35,21 @@ __device__ __forceinline__ void wg_lds_barrier() {
 #endif
 }
 
+// (one wave: the wave-level hand-off of topay_eval.h, no s_barrier)
+template <int NW>
+__device__ __forceinline__ void wg_barrier() {
+  if (NW == 1) lds_sync();
+  else wg_lds_barrier();
+}
+
 // Sum over the workgroup in a fixed order: wave tree (wave_sum), then (w0 + w1) + (w2 + w3).  `red` holds two sets of
 // four partial sums used alternately, so one barrier per reduction suffices (a wave can only write a set again after
 // every wave has passed the barrier that follows the reads of its previous use); `phase` is a workgroup-uniform local
 // counter, and the caller separates reductions that do not share one by a barrier.
 template <int NW>
 __device__ __forceinline__ double wg_combine(lds_dp red, int& phase, int wave, double wsum) {
-  static_assert(NW == 2 || NW == 4, "waves per trajectory");
+  static_assert(NW == 1 || NW == 2 || NW == 4, "waves per trajectory");
+  if (NW == 1) return wsum;
   lds_dp r = red + (phase & 1) * 4;
   phase++;
   r[wave] = wsum;
@@ -55,9 +63,11 @@ __device__ __forceinline__ double wg_sum(lds_dp red, int& phase, int wave, doubl
 }
 template <int NW>
 __device__ __forceinline__ double wg_max(lds_dp red, int& phase, int wave, double v) {
+  const double wm = wave_max(v);
+  if (NW == 1) return wm;
   lds_dp r = red + (phase & 1) * 4;
   phase++;
-  r[wave] = wave_max(v);
+  r[wave] = wm;
   wg_lds_barrier();
   double m = r[0] > r[1] ? r[0] : r[1];
   if (NW == 4) {
@@ -123,7 +133,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     c_Tp[3 * N + tid] = T4; c_Tp[4 * N + tid] = T5;
     c_gdT[tid] = 0.0;
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   if (tid == 0) {
     BAND(0, 0) = 1.0; BAND(1, 1) = 1.0; BAND(2, 2) = 2.0;
   }
@@ -169,7 +179,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     else v = sigmoidC2(Vq[i * 7 + dq], P.joint_pos_limit_max[dq]);
     cL[d * rows + 6 * i + 5] = v;
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   // LU without pivoting on wave 0 (banded_system.hpp:66-91); the other waves wait at the barrier below
   if (wave == 0) {
     const int t = lane / 7 + 1, u = lane - (lane / 7) * 7;
@@ -187,16 +197,16 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
       lds_sync();
     }
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   for (int t = tid; t < rows; t += NT) rdiag[t] = 1.0 / BAND(t, t);
-  wg_lds_barrier();
+  wg_barrier<NW>();
   if (tid < 9) {
     band_sweep<0>(cL + tid * rows, band, rdiag, rows);
     band_sweep<1>(cL + tid * rows, band, rdiag, rows);
   }
   for (int t = tid; t < 14 * rows; t += NT) c_lu[t] = c_X[t];
   C.cl_in_lds = 1;
-  wg_lds_barrier();
+  wg_barrier<NW>();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -318,7 +328,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
 
   // =========================== sweep 1, phase B: sample bodies, one pass per wave and round
   double carryx = 0.0, carryy = 0.0;   // XY prefix carried across passes: the totals of the passes before `pc`, added in order
@@ -375,7 +385,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     // the costs of this round's passes, added lane by lane in pass order; early rejection tested after every pass
     lds_dp cs = csr + (k & 1) * (NW * 64);
     cs[wave * 64 + lane] = cst_out;
-    wg_lds_barrier();
+    wg_barrier<NW>();
 #pragma unroll
     for (int q = 0; q < NW; q++) {
       const int p2 = k * NW + q;
@@ -409,7 +419,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       c_pcs[2 * tid] = P.s1_path_pos_weight * 2.0 * ex;
       c_pcs[2 * tid + 1] = P.s1_path_pos_weight * 2.0 * ey;
     }
-    wg_lds_barrier();
+    wg_barrier<NW>();
   } else {
     const double Tm = tid < N ? c_Tp[tid] : 0.0;
     const double avg = wg_sum<NW>(c_red, rp, wave, Tm) / N;
@@ -490,7 +500,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       const unsigned long long mk = __ballot(jva);
       if (lane == 0) jmask[wave] = mk;
     }
-    wg_lds_barrier();
+    wg_barrier<NW>();
     // row accumulation: the samples of the row's piece in ascending order, pass by pass (the one-wave order)
 #pragma unroll
     for (int r = 0; r < RMAX; r++) {
@@ -570,7 +580,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
             }
           }
         }
-        wg_lds_barrier();   // every row thread is done with the pass buffers
+        wg_barrier<NW>();   // every row thread is done with the pass buffers
         if (jva) {
 #pragma unroll
           for (int q = 0; q < 7; q++) {
@@ -578,7 +588,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
             pbuf[(7 + q) * 64 + lane] = g2[q];
           }
         }
-        wg_lds_barrier();
+        wg_barrier<NW>();
         for (int q2 = 0; q2 < NW; q2++) {
           unsigned long long todo = jmask[q2];
           lds_cdp pq = pball + q2 * (15 * 64);
@@ -608,14 +618,14 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
         }
       }
     }
-    wg_lds_barrier();   // end of the round: the pass buffers and the masks are free again
+    wg_barrier<NW>();   // end of the round: the pass buffers and the masks are free again
   }
 
   if (STAGE == 2) {
     const double all = wg_sum<NW>(c_red, rp, wave, mt_add_all);
     if (tid < N) c_gdT[tid] += all + mt_add_own;
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   // =========================== sweep 2: backward, XY-gradient chain ===========================
   if (!bad) {
     if (STAGE == 2) {   // phase A: pass totals of the positional gradients in the suffix scan's own order
@@ -632,7 +642,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
           }
         }
       }
-      wg_lds_barrier();
+      wg_barrier<NW>();
     }
     double rcx = chain0x, rcy = chain0y;   // chain carried across passes: the totals of the passes after `pc - 1`, added in descending order
     pc = npass;
@@ -691,7 +701,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       }
       pbuf[0 * 64 + lane] = v0; pbuf[1 * 64 + lane] = v1; pbuf[2 * 64 + lane] = v2; pbuf[3 * 64 + lane] = v3;
       pbuf[4 * 64 + lane] = vT;
-      wg_lds_barrier();
+      wg_barrier<NW>();
 #pragma unroll
       for (int r = 0; r < RMAX; r++) {
         if (ract[r]) {
@@ -732,7 +742,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
           }
         }
       }
-      wg_lds_barrier();
+      wg_barrier<NW>();
     }
   } else {
     penalty_cost = 1.0e+22;
@@ -744,7 +754,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       for (int q = 0; q < 7; q++) aq[r][q] = 0.0;
     }
     if (tid < N) c_gdT[tid] = 0.0;
-    wg_lds_barrier();
+    wg_barrier<NW>();
   }
 
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
@@ -798,12 +808,12 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       for (int d = 0; d < 9; d++) c_adj[d * rows + rrow[r]] = tot[r][d];
     }
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   if (tid < 9) {
     band_sweep<2>(c_adj + tid * rows, band, rdiag, rows);
     band_sweep<3>(c_adj + tid * rows, band, rdiag, rows);
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -839,7 +849,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       rdiag[row] = part;
     }
   }
-  wg_lds_barrier();
+  wg_barrier<NW>();
   double gdT_tot = 0.0;
   if (tid < N) {
     const int i = tid;

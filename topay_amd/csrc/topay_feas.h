@@ -139,7 +139,7 @@ __device__ __forceinline__ void feasibility_gate(const FeasIO& F, const TOPAY_GL
     for (double t = 0.0; t < Ttot && k < F.cap_samples; t += res) F.tk[k++] = t;
     nsamp = k;
   }
-  __syncthreads();  // cseq / tk stores become visible to the other lanes
+  wave_global_sync();  // cseq / tk stores become visible to the other lanes
   nsamp = (long long)__shfl((int)nsamp, 0);
 
   // ---- 3. samples
@@ -286,7 +286,7 @@ __device__ __forceinline__ void playback(const FeasIO& F, int nq, const double* 
     carryx += __shfl(sx, 63);
     carryy += __shfl(sy, 63);
   }
-  __syncthreads();
+  wave_global_sync();
   const long long nseq = num / approx_res + 1;
   if (seq_out) {
     for (long long k = lane; k < nseq; k += 64) {

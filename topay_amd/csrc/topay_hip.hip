@@ -60,12 +60,12 @@ __device__ __forceinline__ long long uniform_i64(long long v) {
 }
 
 // LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
-template <int NW>
+template <int NW, bool MWE>
 __host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds, int compact) {
-  return NW == 1 ? lds_doubles(Nmax_lds) : lds_doubles_mw(Nmax_lds, NW, compact);
+  return !MWE ? lds_doubles(Nmax_lds) : lds_doubles_mw(Nmax_lds, NW, compact);
 }
 
-template <int RMAX, int NW>
+template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int compact) {
   constexpr int NT = 64 * NW;
   C.tid = threadIdx.x;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
   C.red = nullptr; C.adj = nullptr; C.compact = 0; C.cl_in_lds = 1;
-  if (NW == 1) carve(C, TOPAY_LDS_PTR, Nmax_lds);
+  if (!MWE) carve(C, TOPAY_LDS_PTR, Nmax_lds);
   else carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
   fill_power_table(C.pw, C.lane);
   for (int t = C.tid; t < 27; t += NT) {
@@ -118,13 +118,13 @@ __device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& B
 }
 
 // test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
-template <int RMAX, int NW>
+template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int compact, int repeats) {
   const int b = Bt.order[blockIdx.x];
   const bool commit = (stage & 16) != 0;
   stage &= 15;
   EvalCtx C;
-  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   const long long no = uniform_i64(Bt.noff[b]);
   C.x = (glb_cdp)(Bt.x + no);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
     GradGate gate;
     gate.always = !cost_only; gate.has_early = false; gate.finit = 0.0; gate.thr = -1.0e300; gate.early = 0.0;
     gate.early_ok = false; gate.skip_thr = 0.0;
-    if constexpr (NW == 1) {
+    if constexpr (!MWE) {
       if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
       else f = eval_cost_grad<2, RMAX>(C, mp, gate);
     } else {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
   }
 }
 
-template <int RMAX, int NW>
+template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
   constexpr int NT = 64 * NW;
   const unsigned long long t_begin = wall_clock64();
@@ -174,9 +174,9 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW, MWE>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
   const long long no = uniform_i64(Bt.noff[b]);
   const int n = C.n;
   SolveIO S;
@@ -193,18 +193,57 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   S.stats = (glb_ip)(Bt.stats + (size_t)b * 8);
   S.trace = Bt.trace ? (glb_dp)(Bt.trace + (size_t)b * Bt.trace_cap) : (glb_dp)nullptr;
   S.trace_cap = Bt.trace_cap;
+  const int grp = Bt.group_id ? __builtin_amdgcn_readfirstlane(Bt.group_id[b]) : -1;
+  S.grp_tau = (grp >= 0 && Bt.cancel_budget > 0) ? (TOPAY_GLB int*)(Bt.group_tau + grp) : (TOPAY_GLB int*)nullptr;
+  S.cancel_flag = (const TOPAY_GLB int*)Bt.cancel_flag;
+  S.cancel_budget = Bt.cancel_budget;
   // x <- x0
   {
     const double* x0 = Bt.x0 + (size_t)b * (10 * TOPAY_MAX_N - 8);
     for (int e = C.tid; e < C.n; e += NT) S.x[e] = x0[e];
   }
-  int success = 0;
+  int success = 0, interrupted = 0;
   double cost = 0.0;
-  solve_trajectory<RMAX, NW>(C, mp, S, Bt.s1_past[b], pf, success, cost);
+  solve_trajectory<RMAX, NW, MWE>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
   // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
   __syncthreads();
   store_result<NW>(C, Bt, b);
+  if (Bt.gate_in_solve) {
+    // printConstraintsSituations of the returned trajectory (planner.cpp:878-880) by wave 0, from the result blocks just
+    // written; panels and sample times go to the candidate's L-BFGS history blocks, which are dead now
+    __syncthreads();
+    int* fl = Bt.feas_flags + 2 * b;
+    if (interrupted) {
+      if (C.tid == 0) { fl[0] = 0; fl[1] = 0; }
+    } else if (threadIdx.x < 64) {
+      const long long po = uniform_i64(Bt.poff[b]);
+      const long long hist_doubles = (long long)Bt.hist_m * C.n;
+      FeasIO F;
+      F.coef = Bt.coef + 54 * po;
+      F.T = Bt.T + po;
+      F.N = C.N;
+      F.x0 = C.sx; F.y0 = C.sy;
+      F.th0 = Bt.head[(size_t)b * 27];
+      F.cseq = Bt.hist_s + (long long)Bt.hist_m * no;
+      F.tk = Bt.hist_y + (long long)Bt.hist_m * no;
+      F.cap_panels = hist_doubles / 2 - 1;
+      F.cap_samples = hist_doubles;
+      F.report = Bt.feas_report + (size_t)b * 38;
+      F.feasible = fl;
+      feasibility_gate(F, mp);
+      // first feasible success of its planning call: its work clock opens the 100 ms (cancel_budget) window of the others
+      if (S.grp_tau && success) {
+        wave_global_sync();
+        if (C.tid == 0 && fl[0]) {
+          const int clock = (S.stats[2] + S.stats[5]) * C.N;
+          atomicMin((int*)S.grp_tau, clock);
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (C.tid == 0) {
+    if (Bt.interrupted) Bt.interrupted[b] = interrupted;
     Bt.success[b] = success;
     Bt.cost[b] = cost;
     Bt.xyerr[2 * b] = C.fxe0;
@@ -227,7 +266,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX, int NW>
+template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int compact, int my_class) {
   const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
@@ -250,7 +289,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX, NW>(B, maps, Nmax_lds, compact, B.order[off + pos]);
+      solve_one<RMAX, NW, MWE>(B, maps, Nmax_lds, compact, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -263,39 +302,39 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // length); a resident workgroup that fetches its next candidate itself leaves no slot idle and starts candidates
 // strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
 // not (nothing is shared between candidates).
-template <int RMAX, int NW>
+template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact) {
-  drain_queues<RMAX, NW>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
+  drain_queues<RMAX, NW, MWE>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
 // One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32 / 42 / 64.  Several waves per trajectory
 // (topay_eval_mw.h): k_solve<rows per thread>w<waves>, rows <= 64 x waves x rows per thread.
-#define TOPAY_SOLVE_KERNEL(NAME, R, W)                                                                              \
+#define TOPAY_SOLVE_KERNEL(NAME, R, W, M)                                                                           \
   __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds, int compact) { \
-    solve_body<R, W>(Bt, maps, Nmax_lds, compact);                                                                  \
+    solve_body<R, W, M>(Bt, maps, Nmax_lds, compact);                                                               \
   }
-#define TOPAY_EVAL_KERNEL(NAME, R, W)                                                                               \
+#define TOPAY_EVAL_KERNEL(NAME, R, W, M)                                                                            \
   __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds, int compact) { \
-    eval_body<R, W>(Bt, maps, stage, Nmax_lds, compact, repeats);                                                   \
+    eval_body<R, W, M>(Bt, maps, stage, Nmax_lds, compact, repeats);                                                \
   }
-TOPAY_SOLVE_KERNEL(k_solve1, 1, 1)
-TOPAY_SOLVE_KERNEL(k_solve2, 2, 1)
-TOPAY_SOLVE_KERNEL(k_solve3, 3, 1)
-TOPAY_SOLVE_KERNEL(k_solve4, 4, 1)
-TOPAY_SOLVE_KERNEL(k_solve6, 6, 1)
-TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2)
-TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4)
-TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4)
-TOPAY_EVAL_KERNEL(k_eval1, 1, 1)
-TOPAY_EVAL_KERNEL(k_eval2, 2, 1)
-TOPAY_EVAL_KERNEL(k_eval3, 3, 1)
-TOPAY_EVAL_KERNEL(k_eval4, 4, 1)
-TOPAY_EVAL_KERNEL(k_eval6, 6, 1)
-TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2)
-TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2)
-TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4)
-TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4)
+TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, false)
+TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, false)
+TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, false)
+TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, false)
+TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, false)
+TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, true)
+TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, true)
+TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, true)
+TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, true)
+TOPAY_EVAL_KERNEL(k_eval1, 1, 1, false)
+TOPAY_EVAL_KERNEL(k_eval2, 2, 1, false)
+TOPAY_EVAL_KERNEL(k_eval3, 3, 1, false)
+TOPAY_EVAL_KERNEL(k_eval4, 4, 1, false)
+TOPAY_EVAL_KERNEL(k_eval6, 6, 1, false)
+TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2, true)
+TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2, true)
+TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, true)
+TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4, true)
 
 // feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
 __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
@@ -465,6 +504,7 @@ struct ClassDef {
   int max_n, rmax, nw;
   solve_kernel_t solve;
   eval_kernel_t eval;
+  int mwe = 0;   // the evaluation of topay_eval_mw.h (always for nw > 1); with one wave: in its compact LDS layout
 };
 static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
@@ -481,6 +521,10 @@ static const ClassDef* class_table() {
     else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4};
     if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6};
     else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4};
+    for (int k = 4; k < TOPAY_NBUCKET; k++) t[k].mwe = t[k].nw > 1;
+    // (The templates also instantiate with one wave -- <R, 1, true>: the register-accumulator evaluation in its compact
+    // 138 N-double LDS layout.  Measured for the common classes in round 3: bit-identical results, 1.7 % slower per step,
+    // and no more resident workgroups once the long classes run on several waves; not built.)
     return t;
   }();
   return tab;
@@ -488,10 +532,12 @@ static const ClassDef* class_table() {
 static const int kLdsDoublesPerCU = 160 * 1024 / 8;
 // compact LDS layout (topay_eval_mw.h) when the full one does not fit a compute unit
 static int class_compact(const ClassDef& cd, int nm) {
-  return cd.nw > 1 && lds_doubles_mw(nm, cd.nw, 0) + 8 + 48 > kLdsDoublesPerCU ? 1 : 0;
+  if (!cd.mwe) return 0;
+  if (cd.nw == 1) return 1;   // one wave: LDS is what limits how many workgroups share a compute unit
+  return lds_doubles_mw(nm, cd.nw, 0) + 8 + 48 > kLdsDoublesPerCU ? 1 : 0;
 }
 static size_t class_lds_bytes(const ClassDef& cd, int nm) {
-  const int d = cd.nw == 1 ? lds_doubles(nm) : lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
+  const int d = !cd.mwe ? lds_doubles(nm) : lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
   return (size_t)(d + 8 + 48) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [48]
 }
 
@@ -542,6 +588,13 @@ struct topay_ctx {
   int n_launched = 0;        // candidates the pending solve launched
   int n_gate = 0;            // ... of which the dispatch gate waits for (the classes of up to 32 pieces)
   bool gate = true;
+  bool gate_in_solve = true;   // feasibility gate by the solving wave (TOPAY_GATE_IN_SOLVE=0: the separate kernel only)
+  bool gate_done = false;      // the resident flags / report are those of the last solve
+  // cancellation: planning call of every candidate, the window after a call's first feasible success (piece-evaluations)
+  std::vector<int> h_group;
+  int n_groups = 0, cancel_budget = 0;
+  DevBuf group_id, group_tau, interrupted;
+  int* h_cancel = nullptr;     // pinned: topay_cancel
   int gate_timeouts = 0;     // times the dispatch gate gave up waiting (topay_gate_timeouts)
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
@@ -766,6 +819,9 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     HIPCHK(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
     c->h_started = (int*)hp;
     c->h_started[0] = 0;
+    c->h_cancel = c->h_started + 8;   // same pinned block: topay_cancel's flag
+    c->h_cancel[0] = 0;
+    { const char* ge = getenv("TOPAY_GATE_IN_SOLVE"); c->gate_in_solve = !(ge && ge[0] == '0'); }
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
@@ -787,7 +843,7 @@ void topay_destroy(topay_ctx* c) {
   (void)hipSetDevice(c->device);
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
-                    &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->poff, &c->noff, &c->success, &c->cost, &c->stats,
+                    &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->poff, &c->noff, &c->group_id, &c->group_tau, &c->interrupted, &c->success, &c->cost, &c->stats,
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
   for (DevBuf* b : bufs) b->release();
@@ -1231,6 +1287,9 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(elapsed, (size_t)batch * 8);
   ENS(startus, (size_t)batch * 8);
   ENS(hwid, (size_t)batch * 4);
+  ENS(feas_flags, (size_t)batch * 2 * 4);
+  ENS(feas_report, (size_t)batch * 38 * 8);
+  ENS(interrupted, (size_t)batch * 4);
 #undef ENS
   {
     DevBuf* all[] = {&c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past, &c->map_id, &c->head, &c->tail,
@@ -1253,6 +1312,16 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.elapsed_us = c->elapsed.as<double>();
   d.start_us = c->startus.as<double>();
   d.hw_id = c->hwid.as<int>();
+  d.gate_in_solve = c->gate_in_solve ? 1 : 0;
+  d.feas_flags = c->feas_flags.as<int>();
+  d.feas_report = c->feas_report.as<double>();
+  d.interrupted = c->interrupted.as<int>();
+  HIPCHK(hipMemsetAsync(c->interrupted.p, 0, (size_t)batch * 4, c->stream));
+  // a new batch has no planning-call groups until topay_set_groups says so
+  c->h_group.clear();
+  c->n_groups = 0;
+  d.group_id = nullptr; d.group_tau = nullptr; d.cancel_budget = 0; d.cancel_flag = nullptr;
+  c->gate_done = false;
   HIPCHK(hipMemsetAsync(c->elapsed.p, 0, (size_t)batch * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)batch * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)batch * 8, c->stream));   // never-launched candidates: cost = NaN
@@ -1444,6 +1513,18 @@ topay_status topay_optimize_async(topay_ctx* c) {
     g_last_issued = c;
   }
   HIPCHK(hipEventRecord(c->ev0, c->stream));
+  // cancellation state of this solve: nobody has succeeded yet (clock "infinity"), nothing is interrupted
+  c->h_cancel[0] = 0;
+  {
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_cancel, 0));
+    c->db.cancel_flag = (const int*)dp;
+  }
+  c->db.cancel_budget = c->n_groups > 0 ? c->cancel_budget : 0;
+  if (c->n_groups > 0) HIPCHK(hipMemsetAsync(c->group_tau.p, 0x7f, (size_t)c->n_groups * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->interrupted.p, 0, (size_t)c->B * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->feas_flags.p, 0, (size_t)c->B * 8, c->stream));
+  c->gate_done = false;
   // candidates that were not launched keep success = 0 and cost = NaN
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
@@ -1464,7 +1545,86 @@ topay_status topay_synchronize(topay_ctx* c) {
     c->last_ms = ms;
     c->solved = true;
     c->pending = false;
+    c->gate_done = c->gate_in_solve;
+    if (c->n_groups > 0 && c->cancel_budget > 0) {
+      // The rule, applied once more to the finished batch so that the outcome does not depend on WHEN a candidate saw its
+      // group's clock: a candidate counts iff its own work clock is within cancel_budget of the smallest clock of a
+      // feasible success of its planning call.  (A candidate stopped on the device had already passed that limit with
+      // the clock it saw, which was no smaller than the final one; one that ran to its end before the first success of
+      // its call was published is stopped here.)
+      const int B = c->B;
+      std::vector<int> succ(B), st((size_t)B * 8), fl((size_t)B * 2), intr(B), tau(c->n_groups);
+      HIPCHK(memcpy_sync(c, succ.data(), c->success.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(c, st.data(), c->stats.p, (size_t)B * 32, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(c, fl.data(), c->feas_flags.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(c, intr.data(), c->interrupted.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(c, tau.data(), c->group_tau.p, (size_t)c->n_groups * 4, hipMemcpyDeviceToHost));
+      bool changed = false;
+      for (int b = 0; b < B; b++) {
+        const int g = c->h_group[b];
+        if (g < 0 || intr[b] || c->hN[b] == 0) continue;
+        const long long clock = (long long)(st[(size_t)b * 8 + 2] + st[(size_t)b * 8 + 5]) * c->hN[b];
+        if (clock > (long long)tau[g] + c->cancel_budget) {
+          intr[b] = 1; succ[b] = 0; fl[2 * b] = 0; fl[2 * b + 1] = 0;
+          st[(size_t)b * 8 + 3] = TOPAY_INTERRUPTED;
+          changed = true;
+        }
+      }
+      if (changed) {
+        HIPCHK(memcpy_sync(c, c->success.p, succ.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        HIPCHK(memcpy_sync(c, c->stats.p, st.data(), (size_t)B * 32, hipMemcpyHostToDevice));
+        HIPCHK(memcpy_sync(c, c->feas_flags.p, fl.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+        HIPCHK(memcpy_sync(c, c->interrupted.p, intr.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+      }
+    }
   }
+  return TOPAY_OK;
+}
+
+// == the planner's thread group (planner.cpp:829-952): group_id[b] = planning call (scenario) of candidate b, -1 = none.
+// With a positive cancel budget the candidates of a call that are still running `budget` piece-evaluations after the
+// call's first success that passes the gate are interrupted (threads.interrupt_all() 100 ms after future_succ; the unit
+// is alm_work_budget's: 24 000 = 1 s, so 100 ms = 2400).  Call after topay_set_init_traj; 0 / NULL switches it off.
+topay_status topay_set_groups(topay_ctx* c, const int* group_id, int cancel_budget) {
+  if (!c || !c->have_traj || cancel_budget < 0) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  c->h_group.clear();
+  c->n_groups = 0;
+  c->cancel_budget = cancel_budget;
+  c->db.group_id = nullptr; c->db.group_tau = nullptr;
+  if (!group_id || cancel_budget == 0) return TOPAY_OK;
+  if (!c->gate_in_solve) { set_err("cancellation needs the in-solve feasibility gate (TOPAY_GATE_IN_SOLVE=0 is set)"); return TOPAY_ERR_UNSUPPORTED; }
+  int ng = 0;
+  for (int b = 0; b < c->B; b++) {
+    if (group_id[b] < -1) return TOPAY_ERR_INVALID_ARG;
+    ng = std::max(ng, group_id[b] + 1);
+  }
+  c->h_group.assign(group_id, group_id + c->B);
+  c->n_groups = ng;
+  topay_status s;
+  if ((s = c->group_id.ensure((size_t)c->B * 4)) != TOPAY_OK) return s;
+  if ((s = c->group_tau.ensure((size_t)std::max(1, ng) * 4)) != TOPAY_OK) return s;
+  HIPCHK(memcpy_sync(c, c->group_id.p, group_id, (size_t)c->B * 4, hipMemcpyHostToDevice));
+  c->db.group_id = c->group_id.as<int>();
+  c->db.group_tau = c->group_tau.as<int>();
+  return TOPAY_OK;
+}
+
+// threads.interrupt_all() for the solve in flight (planner.cpp:952): every candidate stops at its next interruption
+// point (top of the ALM loop / next stage-2 evaluation); returns at once, topay_synchronize waits for the kernels.
+topay_status topay_cancel(topay_ctx* c) {
+  if (!c) return TOPAY_ERR_INVALID_ARG;
+  if (c->h_cancel) __atomic_store_n(c->h_cancel, 1, __ATOMIC_RELEASE);
+  return TOPAY_OK;
+}
+
+// interrupted[b] = 1: candidate b was stopped by the cancellation rule or by topay_cancel (no trajectory, success 0)
+topay_status topay_get_interrupted(topay_ctx* c, int* interrupted) {
+  if (!c || !c->have_traj || !interrupted) return TOPAY_ERR_NO_TRAJ;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  HIPCHK(memcpy_sync(c, interrupted, c->interrupted.p, (size_t)c->B * 4, hipMemcpyDeviceToHost));
   return TOPAY_OK;
 }
 
@@ -1869,7 +2029,7 @@ static bool class_for_waves(int N, int nw, ClassDef& out) {
   const int cnt = nw == 1 ? 5 : 2;
   if (!t) return false;
   for (int k = 0; k < cnt; k++)
-    if (N <= t[k].max_n) { out = t[k]; return true; }
+    if (N <= t[k].max_n) { out = t[k]; out.mwe = out.nw > 1; return true; }
   return false;
 }
 
@@ -1930,7 +2090,7 @@ topay_status topay_eval_waves(topay_ctx* c, int stage, int i, int waves, const d
 // trajectory.  Replay and warm-start entry; the cost stored is the stage-2 cost at x.
 topay_status topay_load_solution(topay_ctx* c, int i, const double* x, const double* alm_lambda, const double* alm_rho) {
   topay_status s = eval_one(c, 2, i, x, alm_lambda, alm_rho, nullptr, nullptr, nullptr, true);
-  if (s == TOPAY_OK) c->solved = true;
+  if (s == TOPAY_OK) { c->solved = true; c->gate_done = false; }   // (the gate of a loaded trajectory: the separate kernel)
   return s;
 }
 
@@ -1972,6 +2132,16 @@ topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, 
   if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
   HIPCHK(hipSetDevice(c->device));
   const int B = c->B;
+  if (c->gate_done) {   // the solving waves have gated their own trajectories: verdicts and extremes are resident
+    std::vector<int> fl((size_t)B * 2);
+    HIPCHK(memcpy_sync(c, fl.data(), c->feas_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++) {
+      if (feasible) feasible[b] = fl[2 * b];
+      if (strict) strict[b] = fl[2 * b + 1];
+    }
+    if (report) HIPCHK(memcpy_sync(c, report, c->feas_report.p, (size_t)B * 38 * 8, hipMemcpyDeviceToHost));
+    return TOPAY_OK;
+  }
   // scratch is sized from the longest returned trajectory
   std::vector<double> hT((size_t)c->h_poff[B] + 1);
   HIPCHK(memcpy_sync(c, hT.data(), c->T.p, (size_t)c->h_poff[B] * 8, hipMemcpyDeviceToHost));

@@ -35,6 +35,10 @@ struct SolveIO {
   glb_ip stats;    // [8]
   glb_dp trace;    // optional f-per-evaluation trace
   int trace_cap;
+  // cancellation (DevBatch::group_tau / cancel_flag): null = never
+  TOPAY_GLB int* grp_tau;
+  const TOPAY_GLB int* cancel_flag;
+  int cancel_budget;
 };
 
 // Vector operations on the n-element L-BFGS vectors.  A lane owns EPL / 2 pairs of adjacent elements: register t holds
@@ -87,9 +91,9 @@ __device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int 
   return s;
 }
 
-template <int RMAX, int NW = 1>
+template <int RMAX, int NW = 1, bool MWE = (NW > 1)>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out) {
+                                                 lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out, int& interrupted_out) {
   const DevParams& P = g_P;
   constexpr int NT = 64 * NW;    // threads of this trajectory's workgroup
   const int tid = C.tid, n = __builtin_amdgcn_readfirstlane(C.n);
@@ -109,7 +113,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
   };
   int stage = 1;
   int alm_iter = 0;
-  bool success = false;
+  bool success = false, interrupted = false;
   int st_s1_ret = 0, st_s1_it = 0, st_s1_ev = 0, st_s2_ret = 0, st_s2_it = 0, st_s2_ev = 0, st_sumb = 0;
   C.lam0 = P.alm_init_lambda[0]; C.lam1 = P.alm_init_lambda[1];
   C.rho0 = P.alm_init_rho[0];    C.rho1 = P.alm_init_rho[1];
@@ -129,6 +133,37 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
     const DevLbfgs& lp = stage == 1 ? P.s1_lbfgs : P.s2_lbfgs;
     const int past = stage == 1 ? s1_past : lp.past;
     const int mem = lp.mem_size;
+    // ------------------------------------------------------------------ interruption point (moma_traj_opt.cpp:402, 887)
+    if (stage == 2 && (S.grp_tau || S.cancel_flag)) {
+      // one thread reads (the values may change between two reads), everybody gets its verdict: lane 0's through a
+      // broadcast inside the wave, through the parked-state block across waves
+      int stop = 0;
+      if (tid == 0) {
+        const int clock = (st_s1_ev + st_s2_ev + evals) * C.N;   // piece-evaluations done so far
+#ifndef TOPAY_CPU_EMU
+        if (S.grp_tau) stop = (long long)clock > (long long)__hip_atomic_load(S.grp_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + S.cancel_budget;
+        if (S.cancel_flag) stop |= __hip_atomic_load(S.cancel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+#else
+        if (S.grp_tau) stop = (long long)clock > (long long)*S.grp_tau + S.cancel_budget;
+        if (S.cancel_flag) stop |= *S.cancel_flag != 0;
+#endif
+      }
+      if constexpr (NW == 1) {
+        stop = __shfl(stop, 0);
+      } else {
+        TOPAY_LDS int* sw = (TOPAY_LDS int*)(pf + 46);
+        __syncthreads();
+        if (tid == 0) sw[0] = stop;
+        __syncthreads();
+        stop = sw[0];
+      }
+      if (stop) {
+        st_s2_ret = TOPAY_INTERRUPTED; st_s2_it += k; st_s2_ev += evals;
+        interrupted = true;
+        success = false;
+        break;
+      }
+    }
     // ------------------------------------------------------------------ evaluate at x
     __syncthreads();
     STAMP(C, 9);  // L-BFGS bookkeeping between evaluations
@@ -160,20 +195,21 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       ik[0] = stage; ik[1] = alm_iter; ik[2] = st_s1_ret; ik[3] = st_s1_it; ik[4] = st_s1_ev; ik[5] = st_s2_ret; ik[6] = st_s2_it;
       ik[7] = st_s2_ev; ik[8] = st_sumb; ik[9] = k; ik[10] = end; ik[11] = bound; ik[12] = count; ik[13] = ret; ik[14] = evals;
       ik[15] = mode; ik[16] = ntrace; ik[17] = (brackt ? 1 : 0) | (touched ? 2 : 0);
-      ik[18] = S.nstride; ik[19] = S.trace_cap; ik[20] = s1_past;
+      ik[18] = S.nstride; ik[19] = S.trace_cap; ik[20] = s1_past; ik[21] = S.cancel_budget;
       TOPAY_LDS unsigned long long* qk = (TOPAY_LDS unsigned long long*)(pk + 21);
       qk[0] = (unsigned long long)S.x; qk[1] = (unsigned long long)S.g; qk[2] = (unsigned long long)S.xp;
       qk[3] = (unsigned long long)S.gp; qk[4] = (unsigned long long)S.d; qk[5] = (unsigned long long)S.hist_s;
       qk[6] = (unsigned long long)S.hist_y; qk[7] = (unsigned long long)S.hist_ys; qk[8] = (unsigned long long)S.hist_al;
       qk[9] = (unsigned long long)S.stats; qk[10] = (unsigned long long)S.trace; qk[11] = (unsigned long long)mp;
+      qk[12] = (unsigned long long)S.grp_tau; qk[13] = (unsigned long long)S.cancel_flag;
     }
-    if constexpr (NW == 1) {
+    if constexpr (!MWE) {
       if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
       else f = eval_cost_grad<2, RMAX>(C, mp, gate);
     } else {
       if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW>(C, mp, gate);
       else f = eval_cost_grad_mw<2, RMAX, NW>(C, mp, gate);
-      wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
+      if (NW > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
       rp = 0;
     }
     {
@@ -189,7 +225,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       mode = ui(15); ntrace = ui(16);
       const int fl = ui(17);
       brackt = (fl & 1) != 0; touched = (fl & 2) != 0;
-      S.nstride = ui(18); S.trace_cap = ui(19); s1_past = ui(20);
+      S.nstride = ui(18); S.trace_cap = ui(19); s1_past = ui(20); S.cancel_budget = ui(21);
       const TOPAY_LDS unsigned long long* qk = (const TOPAY_LDS unsigned long long*)(pk + 21);
       auto up = [&](int q) {
         const unsigned long long v = qk[q];
@@ -200,6 +236,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       S.x = (glb_dp)up(0); S.g = (glb_dp)up(1); S.xp = (glb_dp)up(2); S.gp = (glb_dp)up(3); S.d = (glb_dp)up(4);
       S.hist_s = (glb_dp)up(5); S.hist_y = (glb_dp)up(6); S.hist_ys = (glb_dp)up(7); S.hist_al = (glb_dp)up(8);
       S.stats = (glb_ip)up(9); S.trace = (glb_dp)up(10); mp = (const TOPAY_GLB DevMap*)up(11);
+      S.grp_tau = (TOPAY_GLB int*)up(12); S.cancel_flag = (const TOPAY_GLB int*)up(13);
       f = uniform_f64(f);
     }
     evals++;
@@ -545,6 +582,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
   }
   success_out = success ? 1 : 0;
   cost_out = cost;
+  interrupted_out = interrupted ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

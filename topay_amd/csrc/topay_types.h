@@ -126,6 +126,21 @@ struct DevBatch {
   int* queue_next;
   int queue_count[TOPAY_NBUCKET], queue_off[TOPAY_NBUCKET], queue_class;
   int queue_lowest;   // 0: drain the smaller classes' queues too; = queue_class: own queue only (TOPAY_STEAL=0, profiling)
+  // feasibility gate inside the solve (printConstraintsSituations of the returned trajectory by the wave that solved it;
+  // its scratch is the candidate's own, by then dead, L-BFGS history block): verdicts and extremes per candidate
+  int gate_in_solve;
+  int* feas_flags;    // [B][2]
+  double* feas_report;// [B][38]
+  // Cancellation (planner.cpp:943-952: the candidates of one planning call that are still running 100 ms after the first
+  // success are interrupted).  group_id[b] = planning call of candidate b (-1: none); group_tau[g] = smallest work clock
+  // (piece-evaluations, the unit of alm_work_budget) at which a candidate of g finished successfully AND passed the gate;
+  // a candidate whose own clock exceeds group_tau + cancel_budget stops at its next stage-2 evaluation (the reference's
+  // interruption points: moma_traj_opt.cpp:402, 887).  cancel_flag (pinned host memory): topay_cancel, everything stops.
+  const int* group_id;   // [B] or null
+  int* group_tau;        // [groups]
+  int cancel_budget;
+  const int* cancel_flag;
+  int* interrupted;      // [B]
   int* started;       // one counter in pinned host memory: candidates of this launch that have begun (dispatch gate; may be null)
   int gate_maxN;      // ... counting only candidates with at most this many pieces (the common classes, see topay_optimize_async)
   int* hw_id;         // [B] hardware slot the solve ran on: xcc << 16 | se << 12 | cu << 4 | simd  (scheduling diagnostics)
