@@ -1,6 +1,7 @@
 // Minimal C++ caller of the C-ABI (include/topay.h): what the reference-side adapter of INTEGRATION.md does, without
 // Eigen/ROS.  An obstacle-free 20 x 20 x 1.6 m map (distance fields built on the device from empty occupancy grids)
-// and two straight-line candidates; prints success, cost, pieces, feasibility and the end point of each.
+// and two straight-line candidates; prints success, cost, pieces, feasibility and the end point of each, then the
+// scenario's record and its all-gather over RCCL (the multi-GPU exchange, world size 1).
 //   g++ -std=c++17 -Iinclude examples/cabi_demo.cpp -o /tmp/cabi_demo topay_amd/lib/libtopay_hip.so -Wl,-rpath,$PWD/topay_amd/lib
 #include <cmath>
 #include <cstdio>
@@ -68,6 +69,29 @@ int main() {
     std::printf("candidate %d: success %d cost %.6f pieces %d duration %.3f s feasible %d end-point error %.2e m\n", b, ok[b],
                 cost[b], n_pieces[b], total[b], feasible[b], std::sqrt(ex * ex + ey * ey));
     if (!ok[b] || std::sqrt(ex * ex + ey * ey) > 0.01) bad++;
+  }
+  // What a sharded planner does with a solved batch: one 32-byte record per scenario (the winner: shortest duration
+  // among the candidates that succeeded and passed the gate, planner.cpp:999-1010), all-gathered over RCCL.  World size 1
+  // here -- the same calls with (world, rank) of the process on a node with several GPUs; rank 0's id travels out of band.
+  const int scenario_of[batch] = {41, 41};            // both candidates belong to one planning call
+  topay_record_t rec[2], all[2];
+  int n_rec = 0, n_all = 0, winner[2] = {-1, -1};
+  CHECK(topay_scenario_records(ctx, scenario_of, 2, rec, &n_rec, winner));
+  std::printf("scenario %d: winner candidate %d, status %d, duration %.3f s\n", rec[0].scenario_id, rec[0].best_candidate, rec[0].status,
+              rec[0].duration);
+  if (n_rec != 1 || rec[0].scenario_id != 41) bad++;
+  topay_comm_id_t id;
+  const topay_status cs = topay_comm_unique_id(&id);
+  if (cs == TOPAY_OK) {
+    CHECK(topay_comm_init(ctx, &id, 1, 0));
+    CHECK(topay_gather_records(ctx, rec, n_rec, 2, all, &n_all));
+    const bool same = n_all == 1 && all[0].scenario_id == rec[0].scenario_id && all[0].best_candidate == rec[0].best_candidate &&
+                      all[0].status == rec[0].status && all[0].n_pieces == rec[0].n_pieces && all[0].duration == rec[0].duration;
+    std::printf("record gather over RCCL (world 1): %s\n", same ? "ok" : "MISMATCH");
+    if (!same) bad++;
+    CHECK(topay_comm_destroy(ctx));
+  } else {
+    std::printf("record gather skipped: %s\n", topay_last_error());
   }
   topay_destroy(ctx);
   return bad ? 2 : 0;

@@ -374,6 +374,32 @@ topay_status topay_set_groups(topay_ctx* ctx, const int* group_id /* batch */, i
 topay_status topay_cancel(topay_ctx* ctx);
 topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */);
 
+/* ---- multi-GPU: scenarios shard over the GPUs of a node (one process per GPU, nothing of the solve is shared); the one
+ * exchange is the all-gather of a 32-byte record per scenario over RCCL (the reference's selection of
+ * a scenario's winner, planner.cpp:999-1010, stays local).  A C++ planner shards with these four calls and no torch:
+ *   rank 0: topay_comm_unique_id(&id), hands the 128 bytes to the other processes (file, pipe, ROS parameter ...);
+ *   every rank: topay_comm_init(ctx, &id, world, rank); per step topay_scenario_records + topay_gather_records.
+ * RCCL is bound at run time (librccl.so.1; TOPAY_RCCL_LIB overrides): TOPAY_ERR_UNSUPPORTED when it is not there. */
+typedef struct { char internal[128]; } topay_comm_id_t;          /* == ncclUniqueId */
+typedef struct {
+  int scenario_id;      /* caller's id of the scenario (planning call) */
+  int best_candidate;   /* index of the winner among the scenario's candidates, -1: none */
+  int status;           /* 1: a candidate succeeded and passed the gate */
+  int n_pieces;         /* pieces of the winner */
+  double cost;          /* traj_cost of the winner */
+  double duration;      /* total duration of the winner: what the planner ranks by */
+} topay_record_t;
+topay_status topay_comm_unique_id(topay_comm_id_t* id);
+topay_status topay_comm_init(topay_ctx* ctx, const topay_comm_id_t* id, int world, int rank);
+topay_status topay_comm_destroy(topay_ctx* ctx);
+/* One record per scenario of the solved batch resident in ctx, in order of first appearance of its id in scenario_of
+ * (batch entries); winner_index (may be NULL) receives the batch index of each scenario's winner or -1. */
+topay_status topay_scenario_records(topay_ctx* ctx, const int* scenario_of, int cap_records, topay_record_t* records, int* n_records,
+                                    int* winner_index);
+/* ncclAllGather of per_rank records from every rank (n_mine <= per_rank valid ones); all[world x per_rank] receives them
+ * in rank order with the valid ones compacted to the front, *n_valid their number.  Runs on a stream of its own. */
+topay_status topay_gather_records(topay_ctx* ctx, const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* all, int* n_valid);
+
 /* Launch class of a candidate with n_pieces pieces: waves per trajectory (1, 2 or 4) and decision-vector elements per
  * thread of the kernel that solves and (topay_eval) evaluates it.  For parity tooling: the rounding of the solver's dot
  * products depends on how the vectors are divided over the threads.  Any output pointer may be NULL. */

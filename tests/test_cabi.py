@@ -100,6 +100,8 @@ def test_cpp_caller_runs_on_the_device(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("candidate")]
     assert len(lines) == 2 and all("success 1" in ln for ln in lines)
+    # the multi-GPU exchange through the C-ABI (ncclAllGather called by the library, world size 1)
+    assert "record gather over RCCL (world 1): ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_header_is_plain_c99():
@@ -181,3 +183,62 @@ def test_isa_lint_recognises_the_defect_pattern(tmp_path):
     tool = os.path.join(ROOT, "tools", "isa_lint.py")
     assert subprocess.run([sys.executable, tool, str(bad)], capture_output=True).returncode == 1
     assert subprocess.run([sys.executable, tool, str(good)], capture_output=True).returncode == 0
+
+
+def test_scenario_records_match_the_host_selection(hip_lib):
+    """topay_scenario_records (planner.cpp:999-1010 inside the library, for C++ callers) against dist.scenario_records, the
+    numpy restatement bench.py uses, on a solved batch of the lane emulator."""
+    import numpy as np
+    from conftest import EMU_LIB, set_map
+    from harness import workload as wl
+    from topay_amd import dist as tdist
+
+    w, lens, paths, scen = wl.cuboids_batch(3, 2)
+    p = api.default_params(api.load(EMU_LIB))
+    p.s2_lbfgs.max_iterations = 10
+    p.alm_max_outer = 1
+    p.alm_tolerance = 10.0
+    emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(emu, w)
+    ok = emu.optimizeTraj(lens, paths)
+    so = np.array([7, 7, 9, 9, 4, 4], dtype=np.int32)
+    recs, win = emu.scenario_records(so)
+    acc = (ok & emu.check_feasible()).astype(np.int32)
+    ref, rwin = tdist.scenario_records(np.array([7, 9, 4]), so, acc, emu.traj_cost, emu.n_pieces(), emu.total_durations(), return_winners=True)
+    assert list(recs["scenario_id"]) == [7, 9, 4]
+    for r, q in zip(recs, ref):
+        assert r["scenario_id"] == q[0] and r["best_candidate"] == q[1] and r["status"] == q[2]
+        if r["status"]:
+            assert r["n_pieces"] == q[3] and r["cost"] == q[4] and r["duration"] == q[5]
+    assert sorted(int(b) for b in win if b >= 0) == sorted(int(b) for b in rwin)
+    with pytest.raises(api.TopayError):            # no communicator yet
+        emu.gather_records(recs, 4, 1)
+    w.close()
+
+
+@pytest.mark.gpu
+def test_record_gather_through_the_cabi_on_one_gpu():
+    """topay_comm_unique_id / topay_comm_init / topay_gather_records: the library's own ncclAllGather (RCCL bound with dlopen),
+    world size 1, beside a solve in flight on the same context."""
+    import numpy as np
+    from conftest import set_map
+    from harness import workload as wl
+
+    world, start, goal, lens, paths = wl.tables_scenario(2, 8)
+    opt = api.MomaTrajOptBatch(device=0)
+    set_map(opt, world)
+    opt.optimizeTraj(lens, paths)
+    recs, win = opt.scenario_records(np.full(len(lens), 5, dtype=np.int32))
+    assert len(recs) == 1 and recs[0]["scenario_id"] == 5
+    opt.comm_init(opt.comm_unique_id(), 1, 0)
+    other = api.MomaTrajOptBatch(device=0)          # a second context keeps the device busy meanwhile
+    set_map(other, world)
+    other.set_init_traj(lens, paths)
+    other.optimize_async()
+    got = opt.gather_records(recs, 16, 1)
+    other.finish()
+    assert len(got) == 1 and got[0].tobytes() == recs[0].tobytes()
+    empty = opt.gather_records(recs[:0], 16, 1)
+    assert len(empty) == 0
+    opt.comm_destroy()
+    world.close()

@@ -58,6 +58,16 @@ class MeshParams(C.Structure):
                 ("joint_dof_axis", C.c_double * 21)]
 
 
+class CommId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class Record(C.Structure):
+    """topay_record_t: the 32-byte per-scenario record of the multi-GPU exchange."""
+    _fields_ = [("scenario_id", C.c_int), ("best_candidate", C.c_int), ("status", C.c_int), ("n_pieces", C.c_int),
+                ("cost", C.c_double), ("duration", C.c_double)]
+
+
 class MapDesc(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("resolution", C.c_double), ("dims", C.c_int * 3),
                 ("min_boundary", C.c_double * 3), ("max_boundary", C.c_double * 3)]
@@ -123,6 +133,11 @@ def load(path=None):
     L.topay_gate_timeouts.argtypes = [C.c_void_p, c_ip]
     L.topay_class_of.argtypes = [C.c_int, c_ip, c_ip, c_ip]
     L.topay_set_groups.argtypes = [C.c_void_p, c_ip, C.c_int]
+    L.topay_comm_unique_id.argtypes = [C.POINTER(CommId)]
+    L.topay_comm_init.argtypes = [C.c_void_p, C.POINTER(CommId), C.c_int, C.c_int]
+    L.topay_comm_destroy.argtypes = [C.c_void_p]
+    L.topay_scenario_records.argtypes = [C.c_void_p, c_ip, C.c_int, C.POINTER(Record), c_ip, c_ip]
+    L.topay_gather_records.argtypes = [C.c_void_p, C.POINTER(Record), C.c_int, C.c_int, C.POINTER(Record), c_ip]
     L.topay_cancel.argtypes = [C.c_void_p]
     L.topay_get_interrupted.argtypes = [C.c_void_p, c_ip]
     L.topay_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
@@ -572,6 +587,35 @@ class MomaTrajOptBatch:
         out = np.zeros(self.batch, dtype=np.int32)
         _chk(self.L, self.L.topay_get_interrupted(self.h, _ip(out)))
         return out.astype(bool)
+
+    # -- the multi-GPU exchange through the C-ABI (a C++ planner's path; bench.py uses torch.distributed for the same records)
+    def comm_unique_id(self):
+        cid = CommId()
+        _chk(self.L, self.L.topay_comm_unique_id(C.byref(cid)))
+        return cid
+
+    def comm_init(self, cid, world, rank):
+        _chk(self.L, self.L.topay_comm_init(self.h, C.byref(cid), world, rank))
+
+    def comm_destroy(self):
+        _chk(self.L, self.L.topay_comm_destroy(self.h))
+
+    def scenario_records(self, scenario_of):
+        """(records structured array, winner batch indices) of the solved batch: one 32-byte record per scenario."""
+        so = np.ascontiguousarray(scenario_of, dtype=np.int32)
+        cap = len(set(so.tolist()))
+        recs = (Record * max(cap, 1))()
+        n = C.c_int(0)
+        win = np.zeros(max(cap, 1), dtype=np.int32)
+        _chk(self.L, self.L.topay_scenario_records(self.h, _ip(so), cap, recs, C.byref(n), _ip(win)))
+        return np.ctypeslib.as_array(recs)[:n.value].copy() if n.value else np.zeros(0, dtype=np.dtype(Record)), win[:n.value]
+
+    def gather_records(self, records, per_rank, world):
+        rec = np.ascontiguousarray(records)
+        out = (Record * (per_rank * world))()
+        nv = C.c_int(0)
+        _chk(self.L, self.L.topay_gather_records(self.h, rec.ctypes.data_as(C.POINTER(Record)), len(rec), per_rank, out, C.byref(nv)))
+        return np.ctypeslib.as_array(out)[:nv.value].copy()
 
     def gate_timeouts(self):
         n = C.c_int(0)

@@ -15,6 +15,7 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 
 #include "topay_solve.h"
 #include "topay_feas.h"
@@ -595,6 +596,11 @@ struct topay_ctx {
   int n_groups = 0, cancel_budget = 0;
   DevBuf group_id, group_tau, interrupted;
   int* h_cancel = nullptr;     // pinned: topay_cancel
+  // the one exchange of the multi-GPU path: all-gather of per-scenario records over RCCL (topay_comm_init)
+  void* comm = nullptr;        // ncclComm_t
+  int comm_world = 0, comm_rank = 0;
+  hipStream_t comm_stream = nullptr;
+  DevBuf comm_send, comm_recv;
   int gate_timeouts = 0;     // times the dispatch gate gave up waiting (topay_gate_timeouts)
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
@@ -857,6 +863,8 @@ void topay_destroy(topay_ctx* c) {
     std::lock_guard<std::mutex> lk(g_issue_mutex);
     if (g_last_issued == c) g_last_issued = nullptr;
   }
+  (void)topay_comm_destroy(c);
+  c->comm_send.release(); c->comm_recv.release();
   if (c->h_started) (void)hipHostFree(c->h_started);
   if (c->bstart) (void)hipEventDestroy(c->bstart);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1608,6 +1616,20 @@ topay_status topay_set_groups(topay_ctx* c, const int* group_id, int cancel_budg
   HIPCHK(memcpy_sync(c, c->group_id.p, group_id, (size_t)c->B * 4, hipMemcpyHostToDevice));
   c->db.group_id = c->group_id.as<int>();
   c->db.group_tau = c->group_tau.as<int>();
+  // Launch order with cancellation: shortest candidates first inside every class.  Without it the longest go first (they
+  // are the tail of the batch); with it they are the ones the rule interrupts, and they can only be stopped early if the
+  // short candidates of their planning call -- the ones that succeed first on the work clock -- have already run.  The
+  // outcome does not depend on the order (the rule is applied to the candidates' own clocks), only the time saved does.
+  {
+    std::vector<int> ord;
+    for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
+      std::vector<int>& v = c->cls[k];
+      std::stable_sort(v.begin(), v.end(), [&](int a, int b2) { return c->hN[a] < c->hN[b2]; });
+      ord.insert(ord.end(), v.begin(), v.end());
+    }
+    ord.resize(c->B, 0);
+    HIPCHK(memcpy_sync(c, c->order.p, ord.data(), (size_t)c->B * 4, hipMemcpyHostToDevice));
+  }
   return TOPAY_OK;
 }
 
@@ -2212,6 +2234,147 @@ topay_status topay_test_math(topay_ctx* c, int n, const double* a, const double*
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(memcpy_sync(c, out4n, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   da.release(); dbb.release(); dout.release();
+  return TOPAY_OK;
+}
+
+// ---- the multi-GPU exchange behind the C-ABI ------------------------------------------------------------------
+// Scenarios shard over the GPUs of a node, one process per GPU, and nothing of the solve is shared; the one exchange
+// is the all-gather of a fixed-size record per scenario.  RCCL is bound at run time (dlopen: the
+// library has no link-time dependency on it, and inside a process that already carries an RCCL -- torch's -- the same
+// one is used); the collective runs on a stream of its own, so a solve in flight on the context is not waited for.
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, topay_comm_id_t, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {getenv("TOPAY_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.h) break;
+    }
+    if (!api.h) return;
+    api.GetUniqueId = (int (*)(void*))dlsym(api.h, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, topay_comm_id_t, int))dlsym(api.h, "ncclCommInitRank");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.h, "ncclAllGather");
+    api.CommDestroy = (int (*)(void*))dlsym(api.h, "ncclCommDestroy");
+    api.GetErrorString = (const char* (*)(int))dlsym(api.h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { dlclose(api.h); api.h = nullptr; }
+  });
+  return api.h ? &api : nullptr;
+}
+topay_status rccl_fail(const char* what, int rc) {
+  RcclApi* a = rccl_api();
+  set_err(std::string(what) + ": " + (a && a->GetErrorString ? a->GetErrorString(rc) : "RCCL error"));
+  return TOPAY_ERR_NO_DEVICE;
+}
+}  // namespace
+
+topay_status topay_comm_unique_id(topay_comm_id_t* id) {
+  if (!id) return TOPAY_ERR_INVALID_ARG;
+  RcclApi* a = rccl_api();
+  if (!a) { set_err("librccl.so not found (TOPAY_RCCL_LIB names it explicitly)"); return TOPAY_ERR_UNSUPPORTED; }
+  const int rc = a->GetUniqueId(id);
+  return rc == 0 ? TOPAY_OK : rccl_fail("ncclGetUniqueId", rc);
+}
+
+topay_status topay_comm_init(topay_ctx* c, const topay_comm_id_t* id, int world, int rank) {
+  if (!c || !id || world <= 0 || rank < 0 || rank >= world) return TOPAY_ERR_INVALID_ARG;
+  RcclApi* a = rccl_api();
+  if (!a) { set_err("librccl.so not found (TOPAY_RCCL_LIB names it explicitly)"); return TOPAY_ERR_UNSUPPORTED; }
+  HIPCHK(hipSetDevice(c->device));
+  (void)topay_comm_destroy(c);
+  const int rc = a->CommInitRank(&c->comm, world, *id, rank);
+  if (rc != 0) { c->comm = nullptr; return rccl_fail("ncclCommInitRank", rc); }
+  c->comm_world = world;
+  c->comm_rank = rank;
+  if (!c->comm_stream) HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  return TOPAY_OK;
+}
+
+topay_status topay_comm_destroy(topay_ctx* c) {
+  if (!c) return TOPAY_ERR_INVALID_ARG;
+  if (c->comm) {
+    RcclApi* a = rccl_api();
+    if (a) (void)a->CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+  c->comm_world = 0;
+  return TOPAY_OK;
+}
+
+// planner.cpp:999-1010 per scenario: of the candidates that count (optimizeTraj true AND the gate passed) the one with
+// the shortest total duration.  scenario_of[b] = scenario id of candidate b (any ints); one record per distinct id in
+// order of first appearance, best_candidate relative to the scenario's first candidate, -1 / status 0 without a winner.
+topay_status topay_scenario_records(topay_ctx* c, const int* scenario_of, int cap_records, topay_record_t* records, int* n_records,
+                                    int* winner_index /* cap_records, may be null: batch index of each winner or -1 */) {
+  if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
+  if (!scenario_of || !records || !n_records || cap_records < 0) return TOPAY_ERR_INVALID_ARG;
+  const int B = c->B;
+  std::vector<int> ok(B), feas(B);
+  std::vector<double> cost(B), dur(B);
+  topay_status s;
+  if ((s = topay_get_batch(c, ok.data(), cost.data(), nullptr)) != TOPAY_OK) return s;
+  if ((s = topay_check_feasible(c, feas.data())) != TOPAY_OK) return s;
+  if ((s = topay_get_total_durations(c, dur.data())) != TOPAY_OK) return s;
+  std::vector<int> ids, first, best;
+  for (int b = 0; b < B; b++) {
+    int r = -1;
+    for (int k = (int)ids.size() - 1; k >= 0; k--)   // candidates of a scenario are adjacent in practice: found at once
+      if (ids[k] == scenario_of[b]) { r = k; break; }
+    if (r < 0) { ids.push_back(scenario_of[b]); first.push_back(b); best.push_back(-1); r = (int)ids.size() - 1; }
+    if (ok[b] && feas[b] && (best[r] < 0 || dur[b] < dur[best[r]])) best[r] = b;
+  }
+  *n_records = (int)ids.size();
+  if ((int)ids.size() > cap_records) { set_err("topay_scenario_records: cap_records too small"); return TOPAY_ERR_INVALID_ARG; }
+  for (size_t r = 0; r < ids.size(); r++) {
+    topay_record_t& q = records[r];
+    q.scenario_id = ids[r];
+    q.best_candidate = best[r] < 0 ? -1 : best[r] - first[r];
+    q.status = best[r] < 0 ? 0 : 1;
+    q.n_pieces = best[r] < 0 ? 0 : c->hN[best[r]];
+    q.cost = best[r] < 0 ? 0.0 / 0.0 : cost[best[r]];
+    q.duration = best[r] < 0 ? 0.0 / 0.0 : dur[best[r]];
+    if (winner_index) winner_index[r] = best[r];
+  }
+  return TOPAY_OK;
+}
+
+// ncclAllGather of `per_rank` records from every rank (fewer valid ones are padded with scenario_id = INT_MIN); `all`
+// receives world x per_rank records in rank order, *n_valid the number that are not padding (compacted to the front).
+topay_status topay_gather_records(topay_ctx* c, const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* all, int* n_valid) {
+  if (!c || !c->comm) { set_err("topay_gather_records: no communicator (topay_comm_init)"); return TOPAY_ERR_INVALID_ARG; }
+  if (n_mine < 0 || per_rank <= 0 || n_mine > per_rank || (n_mine > 0 && !mine) || !all) return TOPAY_ERR_INVALID_ARG;
+  RcclApi* a = rccl_api();
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = (size_t)per_rank * sizeof(topay_record_t);
+  topay_status s;
+  if ((s = c->comm_send.ensure(bytes)) != TOPAY_OK || (s = c->comm_recv.ensure(bytes * c->comm_world)) != TOPAY_OK) return s;
+  std::vector<topay_record_t> pad((size_t)per_rank);
+  for (int r = 0; r < per_rank; r++) {
+    if (r < n_mine) pad[r] = mine[r];
+    else { pad[r].scenario_id = INT32_MIN; pad[r].best_candidate = -1; pad[r].status = 0; pad[r].n_pieces = 0; pad[r].cost = 0.0; pad[r].duration = 0.0; }
+  }
+  HIPCHK(hipMemcpyAsync(c->comm_send.p, pad.data(), bytes, hipMemcpyHostToDevice, c->comm_stream));
+  const int rc = a->AllGather(c->comm_send.p, c->comm_recv.p, bytes, 0 /* ncclInt8 */, c->comm, c->comm_stream);
+  if (rc != 0) return rccl_fail("ncclAllGather", rc);
+  std::vector<topay_record_t> got((size_t)per_rank * c->comm_world);
+  HIPCHK(hipMemcpyAsync(got.data(), c->comm_recv.p, bytes * c->comm_world, hipMemcpyDeviceToHost, c->comm_stream));
+  HIPCHK(hipStreamSynchronize(c->comm_stream));
+  int n = 0;
+  for (const topay_record_t& q : got)
+    if (q.scenario_id != INT32_MIN) all[n++] = q;
+  for (size_t k = n; k < got.size(); k++) { all[k].scenario_id = INT32_MIN; all[k].best_candidate = -1; all[k].status = 0; all[k].n_pieces = 0; all[k].cost = 0.0; all[k].duration = 0.0; }
+  if (n_valid) *n_valid = n;
   return TOPAY_OK;
 }
 
