@@ -254,6 +254,15 @@ def main():
     elapsed = time.perf_counter() - t_start
     ok = res[-1][0]
     kernel_ms = [r[1] for r in res]
+    # per-candidate figures of the line (evaluation counts, device times, gate verdicts) come from the last TIMED step, read
+    # here: the passes below (serial steps, planner semantics with cancellation) reuse the contexts
+    o_full = opts[(args.steps - 1) % depth]
+    stats = o_full.stats().copy()
+    gate = o_full.check_feasible().copy()          # printConstraintsSituations over the batch (also part of every timed step)
+    waves_of = np.array([o_full.class_of(max(3, n_))[0] for n_ in range(0, 129)], dtype=np.float64)
+    # slot utilisation: device time of the candidates of one step summed (each is measured on the device's constant
+    # clock from its first to its last instruction, times the SIMD slots its workgroup holds) over the SIMD slots there are
+    slot_seconds = float((o_full.elapsed_us() * waves_of[np.clip(o_full.n_pieces(), 0, 128)]).sum() * 1e-6)
     # the same steps strictly one after the other (outside the timed region): the per-launch figures of the roofline
     # block and of the rocprofv3 kernel trace are only well defined when launches of different steps do not overlap
     serial = None
@@ -312,13 +321,8 @@ def main():
                 "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
         o1.close()
         w1.close()
-    stats = opt.stats()
-    # slot utilisation: device time of the candidates of one step summed (each is measured on the device's constant
-    # clock from its first to its last instruction) over the SIMD slots there are, beside the wall time of a step
-    slot_seconds = float(opt.elapsed_us().sum() * 1e-6)
     simd_slots = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
     gate_timeouts = int(sum(o_.gate_timeouts() for o_ in opts))
-    gate = opt.check_feasible()          # printConstraintsSituations over the batch (also part of every timed step)
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
     # overlapping, those spans overlap too, so the average wall time per step is used instead (never smaller than the
@@ -391,7 +395,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3/4/6 (persistent solve: one workgroup per SIMD slot takes candidates from its class's queue; the "
+            "kernel": "k_solve1/2/3 + k_solve2w2/3w2/3w4 (persistent solve: one workgroup of 1, 2 or 4 waves per trajectory takes candidates from its class's queue; the "
                       "up to six class launches of a batch run concurrently)",
             "kernel_ms": kms,
             "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else

@@ -749,8 +749,9 @@ struct World {
 
   // Candidate init paths: candidate 0 = direct A*; others detour through a seeded random free waypoint.
   // Returns states (P x 10 each) appended to `paths`, lengths to `lens`.
+  // dts (optional): the dt of every dense-path entry (the fourth component of getDensePath's output, which MCRRTs::plan needs)
   int initPaths(const double start[10], const double goal[10], int n_cand, uint64_t pseed,
-                std::vector<double>& paths, std::vector<int>& lens) const {
+                std::vector<double>& paths, std::vector<int>& lens, std::vector<double>* dts = nullptr) const {
     const double thr = robot.chassis_colli_radius + 0.1;
     Rng rng(pseed);
     Cell cs = toCell(start[0], start[1]), cg = toCell(goal[0], goal[1]);
@@ -824,6 +825,7 @@ struct World {
         paths.push_back(dense[i][1]);
         paths.push_back(dense[i][2]);
         for (int q = 0; q < 7; q++) paths.push_back(start[3 + q] + f * (goal[3 + q] - start[3 + q]));
+        if (dts) dts->push_back(dense[i][3]);
         acc += dense[i][3];
       }
       lens.push_back((int)dense.size());

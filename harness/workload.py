@@ -218,6 +218,9 @@ class TablesBatch:
         paths = np.zeros(ns * 10)
         L.wl_tables_batch_get(self.h, self.lens.ctypes.data_as(c_ip), self.scen.ctypes.data_as(c_ip), _dp(paths))
         self.paths = paths.reshape(ns, 10)
+        self.dts = np.zeros(ns)             # getDensePath's dt per state: (x, y, theta, dt) is MCRRTs::plan's car path
+        L.wl_tables_batch_get_dt.argtypes = [C.c_void_p, c_dp]
+        L.wl_tables_batch_get_dt(self.h, _dp(self.dts))
         self.scenarios = sorted(set(self.scen.tolist()))
         self._worlds = {}
 
@@ -269,3 +272,82 @@ def dense_path(raw_xy, start_yaw, end_yaw, step_size=1.414, v_max=1.0, w_max=1.2
     L.wl_dense_path.restype = C.c_int
     n = L.wl_dense_path(raw.ctypes.data_as(c_dp), len(raw), step_size, start_yaw, end_yaw, v_max, w_max, out.ctypes.data_as(c_dp), cap)
     return out[:n].copy()
+
+
+# ---- layered joint-space search (MCRRTs::plan) and Reeds-Shepp restatements: libtopay_mcrrt.so --------------------------
+_MLIB = None
+
+
+class McrrtParams(C.Structure):
+    """== topay_mcrrt_params_t (include/topay.h), == topay_wl::McrrtParams (harness/mcrrt.hpp)"""
+    _fields_ = [("goal_sample_rate", C.c_double), ("check_colli_res", C.c_double), ("rs_turning_radius", C.c_double),
+                ("max_iter", C.c_int), ("max_sample_tries", C.c_int), ("node_cap", C.c_int), ("reserved", C.c_int),
+                ("seed", C.c_uint64)]
+
+    def __init__(self, **kw):
+        super().__init__(0.4, 0.01, 1.0e-2, 1000, 64, 2048, 0, 42)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class McrrtNodeRec(C.Structure):
+    _fields_ = [("layer", C.c_int), ("state", C.c_int), ("parent", C.c_int), ("cost", C.c_double), ("q", C.c_double * 7)]
+
+
+def mlib():
+    global _MLIB
+    if _MLIB is None:
+        path = os.path.join(_HERE, "libtopay_mcrrt.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.wl_mcrrt_plan.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, c_dp, C.POINTER(McrrtParams), C.c_uint64, C.c_int, c_dp, c_ip, c_ip,
+                                    c_dp, c_dp, C.c_int, C.POINTER(McrrtNodeRec)]
+        L.wl_rs_path.argtypes = [C.c_double, c_dp, c_dp, c_ip, c_dp]
+        L.wl_rs_path.restype = C.c_double
+        L.wl_rs_interpolate.argtypes = [C.c_double, c_dp, c_dp, C.c_double, c_dp]
+        L.wl_rs_interpolate.restype = None
+        L.wl_mcrrt_u01.argtypes = [C.c_uint64] * 4
+        L.wl_mcrrt_u01.restype = C.c_double
+        _MLIB = L
+    return _MLIB
+
+
+def mcrrt_plan(world, start, end, car_path, params=None, inst=0, track_slack=False, want_nodes=True):
+    """CPU restatement of MCRRTs::plan (mcrrts.cpp:5-231) on `world`.  car_path: [L, 4] (x, y, theta, dt).  Returns a dict:
+    status (1 path / 0 none / -1 node pool full), wb_path [m, 10], stats (8 ints), c_max, min_slack, nodes (structured array:
+    layer, state, parent, cost, q -- in creation order)."""
+    L = mlib()
+    prm = params or McrrtParams()
+    cp = np.ascontiguousarray(car_path, dtype=np.float64).reshape(-1, 4)
+    st = np.ascontiguousarray(start, dtype=np.float64)
+    en = np.ascontiguousarray(end, dtype=np.float64)
+    wb = np.zeros((len(cp), 10))
+    wl_, stats = C.c_int(0), np.zeros(8, dtype=np.int32)
+    cmax, slack = C.c_double(0), C.c_double(0)
+    nodes = (McrrtNodeRec * prm.node_cap)() if want_nodes else None
+    s = L.wl_mcrrt_plan(world.h, _dp(st), _dp(en), len(cp), _dp(cp), C.byref(prm), int(inst), int(track_slack), _dp(wb), C.byref(wl_),
+                        stats.ctypes.data_as(c_ip), C.byref(cmax), C.byref(slack), prm.node_cap, nodes)
+    out = dict(status=int(s), wb_path=wb[:wl_.value].copy(), stats=stats, c_max=cmax.value, min_slack=slack.value, nodes=None)
+    if want_nodes:
+        out["nodes"] = np.ctypeslib.as_array(nodes)[:stats[1]].copy() if stats[1] > 0 else np.zeros(0, dtype=[("layer", "i4")])
+    return out
+
+
+def rs_path(from_pose, to_pose, rho=1.0e-2):
+    """ompl::base::ReedsSheppStateSpace(rho).reedsShepp(from, to) restated: (word 0..17, five signed lengths, distance)."""
+    L = mlib()
+    a = np.ascontiguousarray(from_pose, dtype=np.float64)
+    b = np.ascontiguousarray(to_pose, dtype=np.float64)
+    t, ln = C.c_int(0), np.zeros(5)
+    d = L.wl_rs_path(rho, _dp(a), _dp(b), C.byref(t), _dp(ln))
+    return t.value, ln, d
+
+
+def rs_interpolate(from_pose, to_pose, t, rho=1.0e-2):
+    L = mlib()
+    a = np.ascontiguousarray(from_pose, dtype=np.float64)
+    b = np.ascontiguousarray(to_pose, dtype=np.float64)
+    out = np.zeros(3)
+    L.wl_rs_interpolate(rho, _dp(a), _dp(b), float(t), _dp(out))
+    return out

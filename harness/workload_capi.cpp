@@ -136,6 +136,7 @@ struct TablesBatch {
   std::vector<int> lens;          // per trajectory
   std::vector<int> scen;          // scenario of each trajectory
   std::vector<double> paths;      // ragged
+  std::vector<double> dts;        // dt of every state (dense path)
 };
 
 // Scenarios with index >= g_keep_esdf3d drop their CPU-built 3-D distance field as soon as their init paths exist (it
@@ -152,7 +153,7 @@ void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_
   tb->starts.resize(S);
   tb->goals.resize(S);
   std::vector<std::vector<int>> lens(S);
-  std::vector<std::vector<double>> paths(S);
+  std::vector<std::vector<double>> paths(S), dts(S);
   if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
   std::atomic<int> next(0);
   auto worker = [&]() {
@@ -175,15 +176,16 @@ void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_
         double start[10] = {s3[0], s3[1], s3[2], 0, 0, 0, 0, 0, 0, 0}, goal[10] = {g3[0], g3[1], g3[2], 0, 0, 0, 0, 0, 0, 0};
         Rng ra(seed * 7919 + 2 * attempt), rb(seed * 7919 + 2 * attempt + 1);
         bool ok = w->sampleArm(ra, goal) && w->sampleArm(rb, start);
-        std::vector<double> pth;
+        std::vector<double> pth, dtv;
         std::vector<int> ln;
-        if (ok) ok = w->initPaths(start, goal, n_cand, seed * 104729 + attempt, pth, ln) == n_cand;
+        if (ok) ok = w->initPaths(start, goal, n_cand, seed * 104729 + attempt, pth, ln, &dtv) == n_cand;
         if (!ok) { delete w; continue; }
         if (g_keep_esdf3d >= 0 && sidx >= g_keep_esdf3d) std::vector<double>().swap(w->gm.esdf3d);
         tb->worlds[sidx] = w;
         for (int q = 0; q < 10; q++) { tb->starts[sidx][q] = start[q]; tb->goals[sidx][q] = goal[q]; }
         lens[sidx] = ln;
         paths[sidx] = pth;
+        dts[sidx] = dtv;
         break;
       }
     }
@@ -195,6 +197,7 @@ void* wl_tables_batch_create(int S, int n_cand, uint64_t base_seed, double size_
     if (!tb->worlds[sidx]) continue;  // failed scenario: contributes nothing
     for (int l : lens[sidx]) { tb->lens.push_back(l); tb->scen.push_back(sidx); }
     tb->paths.insert(tb->paths.end(), paths[sidx].begin(), paths[sidx].end());
+    tb->dts.insert(tb->dts.end(), dts[sidx].begin(), dts[sidx].end());
   }
   return tb;
 }
@@ -210,6 +213,12 @@ void wl_tables_batch_get(void* h, int* lens, int* scen, double* paths) {
   std::memcpy(lens, tb->lens.data(), tb->lens.size() * sizeof(int));
   std::memcpy(scen, tb->scen.data(), tb->scen.size() * sizeof(int));
   std::memcpy(paths, tb->paths.data(), tb->paths.size() * sizeof(double));
+}
+// dt of every state of the batch's init paths (getDensePath's fourth component): with (x, y, theta) of the state it is the
+// car path MCRRTs::plan takes
+void wl_tables_batch_get_dt(void* h, double* dt) {
+  TablesBatch* tb = (TablesBatch*)h;
+  std::memcpy(dt, tb->dts.data(), tb->dts.size() * sizeof(double));
 }
 void* wl_tables_batch_world(void* h, int sidx) { return ((TablesBatch*)h)->worlds[sidx]; }
 

@@ -5,7 +5,7 @@
 # the profiler's preloaded library initialises HIP before python starts: the library's own setenv / bench.py's setdefault
 # come too late, so the 24 hardware queues of the shipped configuration are asked for here
 export GPU_MAX_HW_QUEUES=24
-R=${1:-r02}
+R=${1:-r03}
 WL=$2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R${WL:+_$WL}

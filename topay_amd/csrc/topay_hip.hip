@@ -161,6 +161,10 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
   }
 }
 
+// The gate inside the solve kernel is a call: inlined, its 9 000 instructions and their live ranges became part of the
+// solver's register allocation (161 instead of 33 spilled VGPRs in k_solve1).
+__device__ __noinline__ void feasibility_gate_in_solve(const FeasIO F, const TOPAY_GLB DevMap* mp) { feasibility_gate(F, mp); }
+
 template <int RMAX, int NW, bool MWE>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
   constexpr int NT = 64 * NW;
@@ -231,7 +235,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
       F.cap_samples = hist_doubles;
       F.report = Bt.feas_report + (size_t)b * 38;
       F.feasible = fl;
-      feasibility_gate(F, mp);
+      feasibility_gate_in_solve(F, mp);
       // first feasible success of its planning call: its work clock opens the 100 ms (cancel_budget) window of the others
       if (S.grp_tau && success) {
         wave_global_sync();
