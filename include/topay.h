@@ -272,6 +272,47 @@ topay_status topay_connect_check_num(int n_edges, const double* rs_distance, con
 topay_status topay_connect_collision(topay_ctx* ctx, int map_id, int n_edges, const int* piece_num, const double* car_poses,
                                      const double* q_from, const double* q_to, int* collide);
 
+/* == MCRRTs::plan (src/planner/src/mcrrts.cpp:5-231; steer / rewire 336-400; the inline members of
+ * src/planner/include/planner/mcrrts.h:153-348), the layered bidirectional search over the arm joints along a fixed chassis
+ * path that produces optimizeTraj's init path -- n instances (candidate chassis paths) per call, one wavefront each.
+ *   path_len[p], car_paths    chassis path of instance p: path_len[p] entries (x, y, theta, dt) as topay_dense_path /
+ *                             GraphSearch::getDensePath return them (ragged, sum x 4); 2..min(cap_per_path, 255) entries
+ *   start, end                n x 10 full states (x, y, theta, q1..q7); the joints seed the two trees
+ *   wb_len[p], wb_path        the whole-body path: wb_len[p] states of 10 doubles (one per layer) at wb_path + p *
+ *                             cap_per_path * 10; wb_len[p] = 0 when no path was found
+ *   stats (n x 8, optional)   status (1 path, 0 none, -1 node pool full, -2 bad input), nodes, iterations, tree nodes,
+ *                             anti-tree nodes, the two nodes that joined the trees, whole-body collision checks
+ *   c_max (n, optional)       cost of the connection (mcrrts.cpp:74-79)
+ * The chassis poses along a tree edge are ompl::base::ReedsSheppStateSpace(1e-2)'s (mcrrts.h:134, 318-324, 336); OMPL is a
+ * third-party dependency that is not part of the reference's sources, its published algorithm (Reeds & Shepp 1990) is
+ * implemented in the library (topay_reeds_shepp exposes it).  Where the reference is not reproducible the library is
+ * deterministic (topay_mcrrt_params_t): every random draw is a pure function of (seed, first_instance + p, iteration,
+ * slot) instead of a std::mt19937 seeded from std::random_device (mcrrts.h:89), and the 0.2 s wall-clock limits
+ * (params/mcrrts.yaml, mcrrts.cpp:43, 143, mcrrts.h:225) are counts. */
+typedef struct {
+  double goal_sample_rate;     /* mcrrts/goal_sample_rate (0.4) */
+  double check_colli_res;      /* mcrrts/check_colli_res (0.01): spacing of the collision checks along an edge */
+  double rs_turning_radius;    /* ReedsSheppStateSpace(1.0e-2), mcrrts.h:134 */
+  int max_iter;                /* iterations of the main loop (stands in for mcrrts/max_time) */
+  int max_sample_tries;        /* resamplings of sampleState while the sample is in collision (mcrrts.h:225) */
+  int node_cap;                /* nodes per instance; the search fails with status -1 when it needs more */
+  int reserved;
+  unsigned long long seed;
+} topay_mcrrt_params_t;
+void topay_mcrrt_default_params(topay_mcrrt_params_t* p);
+topay_status topay_mcrrt_plan(topay_ctx* ctx, int n, const int* map_ids /* n, NULL = slot 0 */, const int* path_len, const double* car_paths,
+                              const double* start, const double* end, const topay_mcrrt_params_t* params /* NULL = defaults */,
+                              unsigned long long first_instance, int cap_per_path, int* wb_len, double* wb_path, int* stats, double* c_max);
+/* Node table of instance `instance` of the last topay_mcrrt_plan, in creation order (diagnostics, parity tests): layer
+ * (robo_state.first), state (MCRRTNode::NodeState: 1 EXPANDED, 2 IN_TREE, 3 IN_ANTI_TREE), parent (index, -1 none),
+ * cost, q (7 per node).  Up to cap rows; any pointer may be NULL. */
+topay_status topay_mcrrt_nodes(topay_ctx* ctx, int instance, int cap, int* layer, int* state, int* parent, double* cost, double* q);
+/* ompl::base::ReedsSheppStateSpace(rho) for n pose pairs (x, y, theta): distance[i] = distance(from_i, to_i), word[i] /
+ * lengths[i][5] = the shortest path's segment word (0..17, OMPL's reedsSheppPathType numbering) and signed segment lengths
+ * in units of rho, pose[i] = interpolate(from_i, to_i, t[i]) when t is given.  Output pointers may be NULL. */
+topay_status topay_reeds_shepp(topay_ctx* ctx, int n, const double* from, const double* to, const double* t /* n or NULL */, double rho,
+                               double* distance, int* word, double* lengths, double* pose);
+
 /* MomaTraj playback of candidate i (moma_traj_opt.h:26-137): car_seq -- (x, y, theta, t) every 0.1 s from Simpson
  * panels of 0.025 s, what the reference stores in the trajectory object and publishes -- and getState(t) at caller-given
  * times, states[n_times][10] = (x, y, theta, q1..q7).  seq (seq_cap rows of 4 doubles) may be NULL; *n_seq receives the

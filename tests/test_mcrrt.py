@@ -1,0 +1,210 @@
+"""The layered joint-space search of the front-end: topay_mcrrt_plan == MCRRTs::plan
+(/root/reference/src/planner/src/mcrrts.cpp:5-231, 336-400; planner/include/planner/mcrrts.h:153-348) and topay_reeds_shepp ==
+the two calls the search makes into ompl::base::ReedsSheppStateSpace (mcrrts.h:318-324, 336).
+
+Checkers: harness/mcrrt.hpp -- the CPU restatement of the search in the reference's structure (std::map of string keys,
+recursive cost updates, libm) and of OMPL's Reeds-Shepp implementation, candidate by candidate.  OMPL is a third-party
+dependency that is not in /root/reference: the restatement is pinned by closed-form cases only (straight line, rotation
+in place, end point reached for random pose pairs); the product's implementation is structured differently (one table
+of eight base formulas x four symmetries) and is compared with it word by word.
+
+The trees are compared node by node in creation order: layer, state, parent index, joint vector (bit for bit), cost (bit
+for bit), the connecting pair, the counters, c_max and the whole-body path.  Both sides draw the same counter-based random
+numbers (the reference seeds from std::random_device, mcrrts.h:89).  A difference is accepted only for an instance one of
+whose discrete decisions was a tie within rounding (min_slack of the restatement: collision thresholds, ceil of the check
+counts); none has been observed.
+"""
+import numpy as np
+import pytest
+
+from conftest import EMU_LIB, set_map
+from harness import workload as wl
+from topay_amd import api
+
+
+def _instances(tb, sel):
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    lens = tb.lens[sel]
+    car = np.concatenate([np.c_[tb.paths[offs[b]:offs[b + 1], :3], tb.dts[offs[b]:offs[b + 1]]] for b in sel])
+    start = np.array([tb.paths[offs[b]] for b in sel])
+    end = np.array([tb.paths[offs[b + 1] - 1] for b in sel])
+    return lens, car, start, end
+
+
+def _compare(opt, tb, sel, max_iter, seed=7, first=100, min_same=1.0):
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    for s_ in tb.scenarios:
+        set_map(opt, tb.world(s_), map_id=slot[s_])
+    lens, car, start, end = _instances(tb, sel)
+    mid = np.array([slot[tb.scen[b]] for b in sel], dtype=np.int32)
+    prm = opt.mcrrt_params(seed=seed, max_iter=max_iter)
+    wbs, stats, cmax = opt.mcrrt_plan(lens, car, start, end, prm, map_ids=mid, first_instance=first)
+    hp = wl.McrrtParams(seed=seed, max_iter=max_iter)
+    co = np.concatenate([[0], np.cumsum(lens)])
+    same, ties, found = 0, 0, 0
+    for k, b in enumerate(sel):
+        r = wl.mcrrt_plan(tb.world(int(tb.scen[b])), start[k], end[k], car[co[k]:co[k + 1]], hp, inst=first + k, track_slack=True)
+        hn = r["nodes"]
+        ok = list(stats[k, :7]) == list(r["stats"][:7]) and cmax[k] == r["c_max"]
+        if ok:
+            nd = opt.mcrrt_nodes(k, stats[k, 1])
+            hq = np.array([np.array(x) for x in hn["q"]]).reshape(-1, 7)
+            linked = hn["parent"] >= 0
+            ok = ((hn["layer"] == nd["layer"]).all() and (hn["state"] == nd["state"]).all() and (hn["parent"] == nd["parent"]).all()
+                  and (hq == nd["q"]).all() and (hn["cost"][linked] == nd["cost"][linked]).all())
+            ok = ok and len(wbs[k]) == len(r["wb_path"]) and (len(wbs[k]) == 0 or (wbs[k] == r["wb_path"]).all())
+        if ok:
+            same += 1
+        else:
+            assert r["min_slack"] < 1e-9, (k, b, stats[k], r["stats"], r["min_slack"])
+            ties += 1
+        found += int(r["status"] == 1)
+        if r["status"] == 1:   # the path itself: one state per layer, the chassis poses of the dense path, the given end joints
+            wp = r["wb_path"]
+            assert len(wp) == lens[k] and (wp[:, :3] == car[co[k]:co[k + 1], :3]).all()
+            assert (wp[0, 3:] == start[k, 3:]).all() and (wp[-1, 3:] == end[k, 3:]).all()
+    assert same >= min_same * len(sel), (same, ties, len(sel))
+    return same, ties, found, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reeds-Shepp
+# ---------------------------------------------------------------------------------------------------------------------
+def test_reeds_shepp_restatement_known_answers():
+    rho = 0.01
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-4, 4)])
+        d = rng.uniform(0.05, 2.0)
+        h = np.array([np.cos(a[2]), np.sin(a[2]), 0.0])
+        for sgn in (1.0, -1.0):    # straight ahead / straight back: the distance is the Euclidean one
+            _, ln, dist = wl.rs_path(a, a + sgn * d * h, rho)
+            assert abs(dist - d) < 1e-12 and abs(np.abs(ln).sum() * rho - dist) < 1e-15
+        dth = rng.uniform(-3.1, 3.1)   # rotation in place: every unit of arc turns the car by at most one radian
+        _, _, dist = wl.rs_path(a, a + np.array([0.0, 0.0, dth]), rho)
+        assert abs(dist - rho * abs(dth)) < 1e-12
+    worst = 0.0
+    for _ in range(3000):          # interpolate(1) is the goal pose, interpolate(0) the start; distance is symmetric
+        a = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-4, 4)])
+        b = a + np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-3, 3)])
+        rho_ = rng.choice([0.01, 0.05, 0.2])
+        e = wl.rs_interpolate(a, b, 1.0 - 1e-13, rho_)
+        worst = max(worst, np.hypot(e[0] - b[0], e[1] - b[1]), abs(np.angle(np.exp(1j * (e[2] - b[2])))))
+        assert (wl.rs_interpolate(a, b, 0.0, rho_) == a).all() and (wl.rs_interpolate(a, b, 1.0, rho_) == b).all()
+        assert abs(wl.rs_path(a, b, rho_)[2] - wl.rs_path(b, a, rho_)[2]) < 1e-9
+        assert wl.rs_path(a, b, rho_)[2] >= np.hypot(*(b - a)[:2]) - 1e-12
+    assert worst < 1e-9, worst
+
+
+def _rs_compare(opt, n, seed):
+    rng = np.random.default_rng(seed)
+    a = np.c_[rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(-4, 4, n)]
+    b = a + np.c_[rng.uniform(-.2, .2, n), rng.uniform(-.2, .2, n), rng.uniform(-2, 2, n)]
+    b[: n // 6, :2] = a[: n // 6, :2]                    # rotations in place (the dense path's turning entries)
+    h = np.c_[np.cos(a[:, 2]), np.sin(a[:, 2])]
+    k = slice(n // 6, n // 3)
+    b[k, :2] = a[k, :2] + h[k] * rng.uniform(0.01, 1.5, (k.stop - k.start, 1))   # straight moves (its translating entries)
+    b[k, 2] = a[k, 2]
+    t = rng.uniform(0, 1, n)
+    d, w, ln, po = opt.reeds_shepp(a, b, t, rho=0.01)
+    for i in range(n):
+        tw, tl, td = wl.rs_path(a[i], b[i], 0.01)
+        tp = wl.rs_interpolate(a[i], b[i], t[i], 0.01)
+        # what the search uses: the distance and the interpolated pose
+        assert abs(td - d[i]) < 1e-12 and np.allclose(tp[:2], po[i][:2], rtol=0, atol=1e-9), (i, a[i], b[i], td, d[i], tp, po[i])
+        assert abs(np.angle(np.exp(1j * (tp[2] - po[i][2])))) < 1e-9
+        # the word itself, unless the path is degenerate (a straight move is L0 S L0 as well as L0 S R0: arcs of zero length)
+        nseg = lambda word: 3 if word in (0, 1, 12, 13, 14, 15) else (5 if word >= 16 else 4)
+        if np.abs(tl[:nseg(tw)]).min() > 1e-9 and np.abs(ln[i][:nseg(w[i])]).min() > 1e-9:
+            assert tw == w[i] and np.allclose(tl, ln[i], rtol=0, atol=1e-9), (i, a[i], b[i], tw, w[i], tl, ln[i])
+
+
+def test_reeds_shepp_kernel_sources_on_cpu():
+    opt = api.MomaTrajOptBatch(device=0, lib_path=EMU_LIB)
+    _rs_compare(opt, 3000, 3)
+
+
+@pytest.mark.gpu
+def test_reeds_shepp_on_gpu():
+    opt = api.MomaTrajOptBatch(device=0)
+    _rs_compare(opt, 30000, 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the search
+# ---------------------------------------------------------------------------------------------------------------------
+def test_mcrrt_kernel_sources_on_cpu():
+    """The kernel in the lane emulator against the restatement: 32 chassis paths of 4 tables scenarios, searched to the end
+    (up to 1000 iterations, trees of up to 250 nodes)."""
+    tb = wl.TablesBatch(4, 8, base_seed=31337, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0, lib_path=EMU_LIB)
+    same, ties, found, stats = _compare(opt, tb, list(range(len(tb.lens))), 1000)
+    assert found >= 20 and stats[:, 1].max() > 100, (found, stats[:, 1].max())
+    tb.close()
+
+
+def test_mcrrt_caps_and_trivial_cases():
+    tb = wl.TablesBatch(2, 8, base_seed=31337, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0, lib_path=EMU_LIB)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    for s_ in tb.scenarios:
+        set_map(opt, tb.world(s_), map_id=slot[s_])
+    sel = [8, 9, 10]
+    lens, car, start, end = _instances(tb, sel)
+    mid = np.array([slot[tb.scen[b]] for b in sel], dtype=np.int32)
+    # node pool too small: status -1, no path, on both sides
+    prm = opt.mcrrt_params(seed=7, node_cap=6)
+    wbs, stats, _ = opt.mcrrt_plan(lens, car, start, end, prm, map_ids=mid)
+    co = np.concatenate([[0], np.cumsum(lens)])
+    for k, b in enumerate(sel):
+        r = wl.mcrrt_plan(tb.world(int(tb.scen[b])), start[k], end[k], car[co[k]:co[k + 1]], wl.McrrtParams(seed=7, node_cap=6), inst=k)
+        assert stats[k, 0] == r["status"] == -1 and len(wbs[k]) == 0
+    # two-entry chassis path (mcrrts.cpp:25-33): the straight joint interpolation, checked once
+    w = tb.world(int(tb.scen[8]))
+    s2 = start[0].copy()
+    e2 = s2.copy()
+    e2[0] += 0.3 * np.cos(s2[2]); e2[1] += 0.3 * np.sin(s2[2]); e2[3:] += 0.05
+    car2 = np.array([[s2[0], s2[1], s2[2], 0.3], [e2[0], e2[1], e2[2], 0.0]])
+    wbs, stats, _ = opt.mcrrt_plan([2], car2, s2[None], e2[None], opt.mcrrt_params(), map_ids=mid[:1])
+    r = wl.mcrrt_plan(w, s2, e2, car2, wl.McrrtParams(), inst=0)
+    assert stats[0, 0] == r["status"] and len(wbs[0]) == len(r["wb_path"])
+    if r["status"] == 1:
+        assert (wbs[0] == np.stack([s2, e2])).all()
+    # refused inputs
+    with pytest.raises(Exception):
+        opt.mcrrt_plan([1], car2[:1], s2[None], e2[None])
+    tb.close()
+
+
+@pytest.mark.gpu
+def test_mcrrt_on_gpu_matches_restatement():
+    """256 chassis paths of 32 tables scenarios on the device, every tree compared with the restatement node by node."""
+    tb = wl.TablesBatch(32, 8, base_seed=777, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    same, ties, found, stats = _compare(opt, tb, list(range(len(tb.lens))), 1000, seed=11, first=5000, min_same=0.98)
+    print(f"{len(tb.lens)} searches: {same} identical trees, {ties} differing only through a decision within rounding of a tie; "
+          f"{found} found a path; nodes up to {stats[:, 1].max()}, iterations up to {stats[:, 2].max()}")
+    assert found > 0.6 * len(tb.lens)
+    tb.close()
+
+
+@pytest.mark.gpu
+def test_front_end_feeds_the_solver_on_gpu():
+    """dense path -> topay_mcrrt_plan -> topay_set_init_traj -> topay_optimize: the whole-body paths of the device search are
+    valid init paths (the solver's own success rate on them is that of the synthetic generator's)."""
+    tb = wl.TablesBatch(16, 8, base_seed=4242, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    for s_ in tb.scenarios:
+        set_map(opt, tb.world(s_), map_id=slot[s_])
+    sel = list(range(len(tb.lens)))
+    lens, car, start, end = _instances(tb, sel)
+    mid = np.array([slot[tb.scen[b]] for b in sel], dtype=np.int32)
+    wbs, stats, _ = opt.mcrrt_plan(lens, car, start, end, opt.mcrrt_params(seed=3), map_ids=mid)
+    keep = [k for k in sel if stats[k, 0] == 1]
+    assert len(keep) > 0.6 * len(sel)
+    opt.set_init_traj(np.array([len(wbs[k]) for k in keep], dtype=np.int32), np.concatenate([wbs[k] for k in keep]), map_ids=mid[keep])
+    ok = opt.optimize()
+    print(f"{len(keep)} of {len(sel)} searches found a path; the solver converged on {ok.mean():.3f} of them")
+    assert ok.mean() > 0.8
+    tb.close()

@@ -62,6 +62,13 @@ class CommId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]
 
 
+class McrrtParams(C.Structure):
+    """topay_mcrrt_params_t (include/topay.h): the search's parameters, deterministic caps and seed."""
+    _fields_ = [("goal_sample_rate", C.c_double), ("check_colli_res", C.c_double), ("rs_turning_radius", C.c_double),
+                ("max_iter", C.c_int), ("max_sample_tries", C.c_int), ("node_cap", C.c_int), ("reserved", C.c_int),
+                ("seed", C.c_ulonglong)]
+
+
 class Record(C.Structure):
     """topay_record_t: the 32-byte per-scenario record of the multi-GPU exchange."""
     _fields_ = [("scenario_id", C.c_int), ("best_candidate", C.c_int), ("status", C.c_int), ("n_pieces", C.c_int),
@@ -109,6 +116,12 @@ def load(path=None):
     L.topay_get_results.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int, c_ip, c_dp, c_dp, c_dp]
     L.topay_get_polytraj_msg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float),
                                          C.POINTER(C.c_float), C.POINTER(C.c_int8), c_ip]
+    L.topay_mcrrt_default_params.argtypes = [C.POINTER(McrrtParams)]
+    L.topay_mcrrt_default_params.restype = None
+    L.topay_mcrrt_plan.argtypes = [C.c_void_p, C.c_int, c_ip, c_ip, c_dp, c_dp, c_dp, C.POINTER(McrrtParams), C.c_ulonglong, C.c_int, c_ip, c_dp,
+                                   c_ip, c_dp]
+    L.topay_mcrrt_nodes.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.topay_reeds_shepp.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, C.c_double, c_dp, c_ip, c_dp, c_dp]
     L.topay_dense_path.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, C.c_double, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_ip, c_dp]
     L.topay_connect_check_num.argtypes = [C.c_int, c_dp, c_dp, c_dp, C.c_double, c_ip]
     L.topay_connect_collision.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip]
@@ -508,6 +521,51 @@ class MomaTrajOptBatch:
         col = np.zeros(n, dtype=np.int32)
         _chk(self.L, self.L.topay_connect_collision(self.h, map_id, n, _ip(pn), _dp(car), _dp(qf), _dp(qt), _ip(col)))
         return col.astype(bool), pn
+
+    def mcrrt_params(self, **kw):
+        p = McrrtParams()
+        self.L.topay_mcrrt_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def mcrrt_plan(self, lens, car_paths, start, end, params=None, map_ids=None, first_instance=0, cap=None):
+        """MCRRTs::plan for a batch of chassis paths (ragged car_paths [sum lens, 4] = (x, y, theta, dt); start / end [n, 10]).
+        Returns (wb_paths: list of [m, 10] arrays (empty when no path), stats [n, 8], c_max [n])."""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = len(lens)
+        car = np.ascontiguousarray(car_paths, dtype=np.float64).reshape(-1, 4)
+        st = np.ascontiguousarray(start, dtype=np.float64).reshape(n, 10)
+        en = np.ascontiguousarray(end, dtype=np.float64).reshape(n, 10)
+        cap = int(cap or max(2, int(lens.max()) if n else 2))
+        mid = None if map_ids is None else np.ascontiguousarray(map_ids, dtype=np.int32)
+        wl_ = np.zeros(n, dtype=np.int32)
+        wb = np.zeros((n, cap, 10))
+        stats = np.zeros((n, 8), dtype=np.int32)
+        cmax = np.zeros(n)
+        _chk(self.L, self.L.topay_mcrrt_plan(self.h, n, None if mid is None else _ip(mid), _ip(lens), _dp(car), _dp(st), _dp(en),
+                                             None if params is None else C.byref(params), int(first_instance), cap, _ip(wl_), _dp(wb),
+                                             _ip(stats), _dp(cmax)))
+        return [wb[p, :wl_[p]].copy() for p in range(n)], stats, cmax
+
+    def mcrrt_nodes(self, instance, n_nodes):
+        """Node table of one instance of the last mcrrt_plan: dict of layer, state, parent, cost, q ([n_nodes, 7])."""
+        m = int(n_nodes)
+        layer, state, parent = (np.zeros(m, dtype=np.int32) for _ in range(3))
+        cost, q = np.zeros(m), np.zeros((m, 7))
+        _chk(self.L, self.L.topay_mcrrt_nodes(self.h, int(instance), m, _ip(layer), _ip(state), _ip(parent), _dp(cost), _dp(q)))
+        return dict(layer=layer, state=state, parent=parent, cost=cost, q=q)
+
+    def reeds_shepp(self, from_poses, to_poses, t=None, rho=1.0e-2):
+        """ompl ReedsSheppStateSpace(rho): (distance [n], word [n], lengths [n, 5], pose [n, 3] or None)."""
+        a = np.ascontiguousarray(from_poses, dtype=np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(to_poses, dtype=np.float64).reshape(-1, 3)
+        n = len(a)
+        tt = None if t is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (n,)))
+        d, w, ln, po = np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros((n, 5)), np.zeros((n, 3))
+        _chk(self.L, self.L.topay_reeds_shepp(self.h, n, _dp(a), _dp(b), None if tt is None else _dp(tt), float(rho), _dp(d), _ip(w), _dp(ln),
+                                              _dp(po)))
+        return d, w, ln, (po if tt is not None else None)
 
     def alm_state(self):
         """(lambda0, lambda1, rho0, rho1) every candidate finished with."""

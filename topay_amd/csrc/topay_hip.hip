@@ -21,6 +21,7 @@
 #include "topay_feas.h"
 #include "topay_edt.h"
 #include "topay_front.h"
+#include "topay_mcrrt.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
 // One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
@@ -610,6 +611,8 @@ struct topay_ctx {
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
   int simd_slots = 1024;
   DevBuf qnext;
+  DevBuf mc_i, mc_d, mc_k, mc_rs, mc_in;   // node tables, Reeds-Shepp words and inputs of the last topay_mcrrt_plan
+  int mc_n = 0, mc_node_cap = 0;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
@@ -855,7 +858,7 @@ void topay_destroy(topay_ctx* c) {
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->poff, &c->noff, &c->group_id, &c->group_tau, &c->interrupted, &c->success, &c->cost, &c->stats,
                     &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
-                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext};
+                    &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext, &c->mc_i, &c->mc_d, &c->mc_k, &c->mc_rs, &c->mc_in};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); c->map2d_inf[i].release(); c->map2d_crit[i].release(); }
   for (auto& a : c->map_arenas) a.buf.release();
@@ -1903,6 +1906,136 @@ topay_status topay_connect_collision(topay_ctx* c, int map_id, int n_edges, cons
   HIPCHK(hipStreamSynchronize(c->stream));
   d_i.release();
   d_d.release();
+  return TOPAY_OK;
+}
+
+void topay_mcrrt_default_params(topay_mcrrt_params_t* p) {
+  if (!p) return;
+  p->goal_sample_rate = 0.4;      // planner/params/mcrrts.yaml
+  p->check_colli_res = 0.01;
+  p->rs_turning_radius = 1.0e-2;  // mcrrts.h:134
+  p->max_iter = 1000;
+  p->max_sample_tries = 64;
+  p->node_cap = 2048;
+  p->reserved = 0;
+  p->seed = 42;
+}
+
+topay_status topay_mcrrt_plan(topay_ctx* c, int n, const int* map_ids, const int* path_len, const double* car_paths, const double* start,
+                              const double* end, const topay_mcrrt_params_t* prm, unsigned long long first_instance, int cap_per_path,
+                              int* wb_len, double* wb_path, int* stats, double* c_max) {
+  if (!c || n < 0 || cap_per_path < 2 || (n > 0 && (!path_len || !car_paths || !start || !end || !wb_len || !wb_path))) return TOPAY_ERR_INVALID_ARG;
+  topay_mcrrt_params_t P;
+  if (prm) P = *prm;
+  else topay_mcrrt_default_params(&P);
+  if (P.max_iter < 0 || P.max_sample_tries < 1 || P.node_cap < 2 || !(P.check_colli_res > 0.0) || !(P.rs_turning_radius > 0.0)) return TOPAY_ERR_INVALID_ARG;
+  if (n == 0) return TOPAY_OK;
+  std::vector<long long> off((size_t)n + 1, 0);
+  std::vector<int> mid((size_t)n, 0);
+  for (int p = 0; p < n; p++) {
+    if (path_len[p] < 2 || path_len[p] > cap_per_path || path_len[p] > 255) {
+      set_err("topay_mcrrt_plan: chassis path " + std::to_string(p) + " has " + std::to_string(path_len[p]) + " layers (2.." +
+              std::to_string(std::min(cap_per_path, 255)) + " supported: the reference's node key holds the layer in one character)");
+      return TOPAY_ERR_INVALID_ARG;
+    }
+    off[p + 1] = off[p] + path_len[p];
+    mid[p] = map_ids ? map_ids[p] : 0;
+    if (mid[p] < 0 || mid[p] >= TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
+    if (!c->have_map[mid[p]]) return TOPAY_ERR_NO_MAP;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const size_t nn = (size_t)n * P.node_cap, tot = (size_t)off[n];
+  topay_status s;
+  // inputs: map ids, lengths (int), offsets (i64), chassis paths, start, end (f64); outputs: wb_len, stats (int), wb, c_max (f64)
+  const size_t in_i = (size_t)n * 2 + (size_t)n * 9, in_l = (size_t)n + 1, in_d = 4 * tot + 20 * (size_t)n + (size_t)n * cap_per_path * 10 + n;
+  if ((s = c->mc_in.ensure(in_l * 8 + in_d * 8 + in_i * 4)) != TOPAY_OK || (s = c->mc_i.ensure(nn * 5 * 4)) != TOPAY_OK ||
+      (s = c->mc_d.ensure(nn * 8 * 8)) != TOPAY_OK || (s = c->mc_k.ensure(nn * TOPAY_MC_KEYW * 8)) != TOPAY_OK ||
+      (s = c->mc_rs.ensure((size_t)n * 2 * cap_per_path * sizeof(topay::RsPath))) != TOPAY_OK)
+    return s;
+  long long* d_off = c->mc_in.as<long long>();
+  double* d_car = (double*)(d_off + in_l);
+  double* d_start = d_car + 4 * tot;
+  double* d_end = d_start + 10 * (size_t)n;
+  double* d_wb = d_end + 10 * (size_t)n;
+  double* d_cmax = d_wb + (size_t)n * cap_per_path * 10;
+  int* d_mid = (int*)(d_cmax + n);
+  int* d_len = d_mid + n;
+  int* d_wlen = d_len + n;
+  int* d_stats = d_wlen + n;
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), in_l * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_car, car_paths, 4 * tot * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_start, start, 10 * (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_end, end, 10 * (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_mid, mid.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_len, path_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(d_wb, 0, ((size_t)n * cap_per_path * 10 + n) * 8, c->stream));
+  topay_status ps = push_params(c);
+  if (ps != TOPAY_OK) return ps;
+  topay::McrrtBatch B;
+  B.n = n; B.layer_cap = cap_per_path; B.inst_base = first_instance;
+  B.map_id = d_mid; B.car_off = d_off; B.car_len = d_len; B.car = d_car; B.start = d_start; B.end = d_end;
+  B.P.goal_sample_rate = P.goal_sample_rate; B.P.check_colli_res = P.check_colli_res; B.P.rs_rho = P.rs_turning_radius;
+  B.P.max_iter = P.max_iter; B.P.max_sample_tries = P.max_sample_tries; B.P.node_cap = P.node_cap; B.P.reserved = 0; B.P.seed = P.seed;
+  int* ni = c->mc_i.as<int>();
+  B.nd_layer = ni; B.nd_state = ni + nn; B.nd_parent = ni + 2 * nn; B.nd_nchild = ni + 3 * nn; B.nd_mark = ni + 4 * nn;
+  B.nd_cost = c->mc_d.as<double>(); B.nd_q = B.nd_cost + nn; B.nd_key = c->mc_k.as<unsigned long long>();
+  B.rs = (topay::RsPath*)c->mc_rs.p;
+  B.wb_len = d_wlen; B.wb = d_wb; B.stats = d_stats; B.cmax = d_cmax;
+  hipLaunchKernelGGL(topay::k_mcrrt, dim3((unsigned)n), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, B);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(wb_len, d_wlen, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(wb_path, d_wb, (size_t)n * cap_per_path * 80, hipMemcpyDeviceToHost, c->stream));
+  if (stats) HIPCHK(hipMemcpyAsync(stats, d_stats, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+  if (c_max) HIPCHK(hipMemcpyAsync(c_max, d_cmax, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->mc_n = n;
+  c->mc_node_cap = P.node_cap;
+  return TOPAY_OK;
+}
+
+topay_status topay_mcrrt_nodes(topay_ctx* c, int instance, int cap, int* layer, int* state, int* parent, double* cost, double* q) {
+  if (!c || instance < 0 || instance >= c->mc_n || cap < 0) return TOPAY_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t nn = (size_t)c->mc_n * c->mc_node_cap, o = (size_t)instance * c->mc_node_cap;
+  const size_t m = (size_t)std::min(cap, c->mc_node_cap);
+  const int* ni = c->mc_i.as<int>();
+  const double* nd = c->mc_d.as<double>();
+  if (layer) HIPCHK(memcpy_sync(c, layer, ni + o, m * 4, hipMemcpyDeviceToHost));
+  if (state) HIPCHK(memcpy_sync(c, state, ni + nn + o, m * 4, hipMemcpyDeviceToHost));
+  if (parent) HIPCHK(memcpy_sync(c, parent, ni + 2 * nn + o, m * 4, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(memcpy_sync(c, cost, nd + o, m * 8, hipMemcpyDeviceToHost));
+  if (q) HIPCHK(memcpy_sync(c, q, nd + nn + 7 * o, m * 56, hipMemcpyDeviceToHost));
+  return TOPAY_OK;
+}
+
+// ompl::base::ReedsSheppStateSpace(rho): distance and interpolate as the search uses them, for n pose pairs (one thread each)
+topay_status topay_reeds_shepp(topay_ctx* c, int n, const double* from, const double* to, const double* t, double rho, double* distance,
+                               int* word, double* lengths, double* pose) {
+  if (!c || n < 0 || !(rho > 0.0) || (n > 0 && (!from || !to))) return TOPAY_ERR_INVALID_ARG;
+  if (n == 0) return TOPAY_OK;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf d;
+  topay_status s;
+  if ((s = d.ensure((size_t)n * (3 + 3 + 1 + 1 + 5 + 3 + 1) * 8)) != TOPAY_OK) return s;
+  double* d_from = d.as<double>();
+  double* d_to = d_from + 3 * (size_t)n;
+  double* d_t = d_to + 3 * (size_t)n;
+  double* d_dist = d_t + n;
+  double* d_len = d_dist + n;
+  double* d_pose = d_len + 5 * (size_t)n;
+  int* d_word = (int*)(d_pose + 3 * (size_t)n);
+  HIPCHK(memcpy_sync(c, d_from, from, (size_t)n * 24, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, d_to, to, (size_t)n * 24, hipMemcpyHostToDevice));
+  if (t) HIPCHK(memcpy_sync(c, d_t, t, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(topay::k_reeds_shepp, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, (const double*)d_from, (const double*)d_to,
+                     t ? (const double*)d_t : (const double*)nullptr, rho, d_dist, d_word, d_len, d_pose);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (distance) HIPCHK(memcpy_sync(c, distance, d_dist, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (word) HIPCHK(memcpy_sync(c, word, d_word, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (lengths) HIPCHK(memcpy_sync(c, lengths, d_len, (size_t)n * 40, hipMemcpyDeviceToHost));
+  if (pose && t) HIPCHK(memcpy_sync(c, pose, d_pose, (size_t)n * 24, hipMemcpyDeviceToHost));
+  d.release();
   return TOPAY_OK;
 }
 

@@ -278,6 +278,25 @@ __device__ inline void rs_interpolate(const double* from, const RsPath& P, doubl
   out[2] = w;
 }
 
+// distance() and interpolate(from, to, t) for n pose pairs, one thread each (test hook and a caller's own edge checks)
+__global__ void __launch_bounds__(64) k_reeds_shepp(int n, const double* from, const double* to, const double* t, double rho, double* dist, int* word, double* lengths,
+                              double* pose) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  RsPath P;
+  rs_between(from + 3 * (size_t)i, to + 3 * (size_t)i, rho, P);
+  dist[i] = rho * P.total;
+  word[i] = P.type;
+  for (int k = 0; k < 5; k++) lengths[5 * (size_t)i + k] = P.len[k];
+  if (t) {
+    const double ti = t[i];
+    double* o = pose + 3 * (size_t)i;
+    if (ti >= 1.0) { o[0] = to[3 * (size_t)i]; o[1] = to[3 * (size_t)i + 1]; o[2] = to[3 * (size_t)i + 2]; }
+    else if (ti <= 0.0) { o[0] = from[3 * (size_t)i]; o[1] = from[3 * (size_t)i + 1]; o[2] = from[3 * (size_t)i + 2]; }
+    else rs_interpolate(from + 3 * (size_t)i, P, ti, rho, o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the search
 // ---------------------------------------------------------------------------------------------------------------
@@ -444,6 +463,7 @@ __device__ inline int mc_steer(Mc& C, int node, int tl, const double* tq) {
 __device__ inline void mc_link(Mc& C, int par, int child) {
   const int pre = C.parent[child];
   if (pre == par) return;
+  wave_global_sync();   // (every lane has read the old parent before lane 0 replaces it)
   if (C.lane == 0) {
     if (pre >= 0) C.nchild[pre] -= 1;
     C.parent[child] = par;
@@ -454,7 +474,9 @@ __device__ inline void mc_link(Mc& C, int par, int child) {
   mc_load_q(C, par, qp);
   mc_load_q(C, child, qc);
   const double now_cost = C.cost[par] + mc_est(C, C.layer[par], qp, C.layer[child], qc);
-  if (C.cost[child] == now_cost) return;
+  const bool unchanged = C.cost[child] == now_cost;
+  wave_global_sync();
+  if (unchanged) return;
   if (C.lane == 0) C.cost[child] = now_cost;
   if (C.nchild[child] == 0) { wave_global_sync(); return; }
   int stamp = ++C.stamp;
