@@ -76,6 +76,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1536, help="trajectories of the batch timed on the host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial", action="store_true", help="skip the strictly serial steps measured beside a pipelined run")
+    ap.add_argument("--own-maps", action="store_true", help="every context in flight keeps its own copy of the maps (default: shared, topay_share_maps)")
+    ap.add_argument("--front-end", action="store_true",
+                    help="take the init paths from the device's layered joint-space search (topay_mcrrt_plan == MCRRTs::plan along the "
+                         "batch's chassis paths, untimed set-up) instead of the generator's straight joint interpolation; candidates whose "
+                         "search finds no path keep the generator's.  The workload then differs from the default line's and says so")
     ap.add_argument("--no-planner", action="store_true",
                     help="skip the planner-semantics figure (the same steps with the reference's cancellation of a planning call's "
                          "remaining candidates 100 ms after its first accepted one, planner.cpp:943-952), measured beside the line")
@@ -149,7 +154,10 @@ def main():
     for _ in range(depth):
         o_ = api.MomaTrajOptBatch(device=local_rank)
         slot = {s: k for k, s in enumerate(tb.scenarios)}
-        if hires:
+        if opts and not args.own_maps:
+            # the batches in flight share one resident copy of the maps (the reference's optimisers share one GridMap::Ptr)
+            o_.share_maps(opts[0], 0, 1 if hires else len(tb.scenarios))
+        elif hires:
             w = tb.world(0)
             o_.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, map_id=0)
         else:
@@ -165,6 +173,27 @@ def main():
         map_ids_of[id(o_)] = map_ids
         opts.append(o_)
     opt = opts[0]
+    front_end = None
+    if args.front_end and not hires:
+        # MCRRTs::plan for every candidate's chassis path (the dense path's (x, y, theta, dt)) on the device, outside the timed
+        # region like the rest of the front-end; the whole-body paths replace the generator's joints
+        offs_ = np.concatenate([[0], np.cumsum(tb.lens)])
+        car_ = np.c_[tb.paths[:, :3], tb.dts]
+        prm_ = opt.mcrrt_params(seed=42 + rank)
+        tf0 = time.perf_counter()
+        wbs_, mst_, _ = opt.mcrrt_plan(tb.lens, car_, tb.paths[offs_[:-1]], tb.paths[offs_[1:] - 1], prm_, map_ids=map_ids_of[id(opt)],
+                                       first_instance=rank * S * Ccand)
+        tf1 = time.perf_counter() - tf0
+        fe_paths = tb.paths.copy()
+        for k_ in np.nonzero(mst_[:, 0] == 1)[0]:
+            fe_paths[offs_[k_]:offs_[k_ + 1]] = wbs_[k_]
+        tb.paths = fe_paths
+        for o_ in opts:
+            o_.set_init_traj(tb.lens, tb.paths, map_ids=map_ids_of[id(o_)])
+        front_end = {"searches": int(B), "ms": tf1 * 1e3, "searches_per_s": B / tf1, "found_fraction": float((mst_[:, 0] == 1).mean()),
+                     "mean_iterations": float(mst_[:, 2].mean()), "mean_nodes": float(mst_[:, 1].mean()), "max_nodes": int(mst_[:, 1].max()),
+                     "whole_body_checks": int(mst_[:, 7].astype(np.int64).sum()),
+                     "note": "topay_mcrrt_plan, one wave per chassis path, including the copies of its inputs and results; untimed set-up"}
     n_pieces = opt.n_pieces()
     n_not_launched = int((n_pieces <= 0).sum())
     setup_s = time.time() - t0
@@ -319,6 +348,17 @@ def main():
         ms1, _ = o1.last_kernel_ms()
         cfg1 = {"workload": "BASELINE configs[1]: 1 tables scenario x 64 candidates", "solve_ms": float(ms1),
                 "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
+        # the same call in latency mode (topay_set_latency_waves: four waves per candidate -- the device is empty anyway)
+        try:
+            api.set_latency_waves(4)
+            o1.set_init_traj(lens1, paths1)
+            o1.optimize()
+            o1.reset()
+            ok4 = o1.optimize()
+            ms4, _ = o1.last_kernel_ms()
+            cfg1["latency_mode_four_waves"] = {"solve_ms": float(ms4), "success_fraction": float(ok4.mean())}
+        finally:
+            api.set_latency_waves(0)
         o1.close()
         w1.close()
     simd_slots = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
@@ -366,7 +406,9 @@ def main():
                          "trajectories/GPU, both stages + ALM to convergence") if hires else
                         (f"benchmark_tables batch (BASELINE configs[3] per-GPU share: 8192 scenarios / 8 GPUs): {S} "
                          f"scenarios/GPU x {Ccand} candidates = {B} trajectories/GPU, tables map 20x20x1.6 m @0.1 m "
-                         "regenerated per scenario, both stages + ALM to convergence"),
+                         "regenerated per scenario, both stages + ALM to convergence"
+                         + ("; init paths from the device's MCRRTs::plan (--front-end)" if front_end else "")),
+            "front_end": front_end,
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
             "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "max_pieces": int(n_pieces.max()),

@@ -134,6 +134,22 @@ typedef struct topay_ctx topay_ctx;
 /* Fill `p` with the reference defaults (optimizer.yaml + MomaParam). */
 topay_status topay_default_params(topay_params_t* p);
 
+/* Latency mode, process-wide: waves = 4 solves every candidate of up to 64 pieces with four waves (a whole compute unit's
+ * SIMDs) instead of the throughput configuration's one or two; 0 restores the default.  For a planner that optimises the
+ * <= 8 candidates of ONE call at a time (planner.cpp:59, 829, 921-925) the device is empty anyway and the call takes as
+ * long as its longest candidate.  Evaluations are bit-identical to the default's; the solver's sums are divided over four
+ * times the threads, so converged values differ in the last bits.  Not while a solve is in flight. */
+topay_status topay_set_latency_waves(int waves);
+
+/* == MomaTrajOpt::init (src/planner/include/planner/moma_traj_opt.h:845-941) for a caller without a ROS parameter server:
+ * the optimiser parameters from the reference's parameter file (src/planner/params/optimizer.yaml, under
+ * `planner_node: moma_traj_opt:` or at top level).  path_or_text: a file name, or the YAML text itself.  Keys that are
+ * absent keep the value *params has on entry (call topay_default_params first).  ignored (optional, NUL-terminated,
+ * newline-separated): the keys init() reads but this path has no use for -- mean_time_lowb / mean_time_uppb (the
+ * reference's penalty uses the literals 0.5 and 2.0, moma_traj_opt.cpp:1752-1769), first_stage/mean_time_weight,
+ * second_stage/alm_data/... -- and any key init() does not know. */
+topay_status topay_params_from_yaml(const char* path_or_text, topay_params_t* params, char* ignored, int ignored_cap);
+
 /* Create a context on HIP device `device` (use LOCAL_RANK for one process per GPU). */
 topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out);
 void topay_destroy(topay_ctx* ctx);
@@ -164,6 +180,13 @@ topay_status topay_build_esdf(topay_ctx* ctx, int map_id, const topay_map_desc_t
 topay_status topay_build_esdf_batch(topay_ctx* ctx, int n_maps, int first_map_id, const topay_map_desc_t* desc,
                                     const signed char* occ2d, const signed char* occ3d);
 topay_status topay_get_map(topay_ctx* ctx, int map_id, double* esdf2d, double* esdf3d, double* build_ms);
+
+/* Map slots first_map_id .. first_map_id + n_maps - 1 of `ctx` become references to the resident maps of `owner` (same
+ * device), without a copy: the maps are read-only for every entry point but the three that fill a slot.  The reference
+ * hands one GridMap::Ptr to all of its optimisers (planner.cpp:59-75: every MomaTrajOpt gets the planner's grid_map);
+ * here the contexts of the batches in flight share one set of fields the same way.  `owner` must outlive the use of
+ * the shared slots and must not rebuild them while `ctx` solves. */
+topay_status topay_share_maps(topay_ctx* ctx, topay_ctx* owner, int first_map_id, int n_maps);
 
 /* All five fields of GridMap::updateESDF (src/map/src/grid_map.cpp:125-521).  Besides esdf2d and esdf3d (above) the
  * reference builds two more 2-D fields for its front-end:

@@ -160,10 +160,16 @@ planner_node:
     assert list(p.alm_init_rho) == [2.0e4, 3.0e4] and p.alm_tolerance == 0.02 and list(p.alm_gamma) == list(d.alm_gamma)
     assert p.s2_mani_pos_weight == d.s2_mani_pos_weight and p.max_v == d.max_v       # untouched keys keep the defaults
     assert sorted(ignored) == ["mean_time_lowb", "no_such_key", "second_stage/alm_data/max_iter"]
+    # the library's own loader (topay_params_from_yaml, what a C++ planner calls): same fields, same report
+    from conftest import EMU_LIB
+    pc, ignored_c = api.params_from_yaml_c(text, lib=api.load(EMU_LIB))
+    assert bytes(pc) == bytes(p) and sorted(ignored_c) == sorted(ignored)
     ref = "/root/reference/src/planner/params/optimizer.yaml"
     if os.path.exists(ref):      # build container only: the reference's own file gives exactly the built-in defaults
         q, ign = api.params_from_yaml(ref)
         assert bytes(q) == bytes(d)
+        qc, ign_c = api.params_from_yaml_c(ref, lib=api.load(EMU_LIB))
+        assert bytes(qc) == bytes(d) and sorted(ign_c) == sorted(ign)
         assert sorted(ign) == ["first_stage/mean_time_weight", "mean_time_lowb", "mean_time_uppb", "second_stage/alm_data/epsilon_con",
                                "second_stage/alm_data/max_iter"]
 

@@ -29,6 +29,23 @@ def test_init_traj_matches_oracle(emu, cuboids_small):
         assert np.allclose(emu.get_x(b), o.get_x(), rtol=0, atol=1e-12)
 
 
+def test_shared_map_slots_give_the_owner_results(emu, cuboids_small):
+    """topay_share_maps: a second context that borrows the first one's resident map evaluates to the same bits (the
+    reference's optimisers all hold the planner's one GridMap::Ptr, planner.cpp:59-75)."""
+    cs = cuboids_small
+    other = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    with pytest.raises(api.TopayError):
+        other.set_init_traj(cs["lens"], cs["paths"])          # no map yet
+    other.share_maps(emu, 0, 1)
+    other.set_init_traj(cs["lens"], cs["paths"])
+    for b in (0, 3):
+        x = emu.get_x(b)
+        f0, g0, _ = emu.eval(2, b, x, [0.1, 0.2], [1e4, 1e4])
+        f1, g1, _ = other.eval(2, b, x, [0.1, 0.2], [1e4, 1e4])
+        assert f0 == f1 and (g0 == g1).all()
+    other.close()
+
+
 @pytest.mark.parametrize("stage", [1, 2])
 def test_eval_matches_oracle(emu, cuboids_small, stage):
     cs = cuboids_small

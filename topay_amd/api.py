@@ -257,6 +257,28 @@ def params_from_yaml(source, base=None, lib=None):
     return p, ignored
 
 
+def set_latency_waves(waves, lib=None):
+    """Process-wide latency mode (topay_set_latency_waves): 4 = every candidate up to 64 pieces on four waves, 0 = default."""
+    L = lib or load()
+    L.topay_set_latency_waves.argtypes = [C.c_int]
+    _chk(L, L.topay_set_latency_waves(int(waves)))
+
+
+def params_from_yaml_c(source, base=None, lib=None):
+    """The library's own loader (topay_params_from_yaml, for C / C++ callers): same mapping as params_from_yaml."""
+    L = lib or load()
+    p = Params()
+    if base is not None:
+        C.memmove(C.byref(p), C.byref(base), C.sizeof(Params))
+    else:
+        _chk(L, L.topay_default_params(C.byref(p)))
+    buf = C.create_string_buffer(4096)
+    L.topay_params_from_yaml.argtypes = [C.c_char_p, C.POINTER(Params), C.c_char_p, C.c_int]
+    _chk(L, L.topay_params_from_yaml(str(source).encode(), C.byref(p), buf, 4096))
+    ign = buf.value.decode()
+    return p, ([x for x in ign.split("\n") if x] if ign else [])
+
+
 def _chk(L, status):
     if status != 0:
         raise TopayError(f"topay status {status}: {L.topay_last_error().decode()}")
@@ -521,6 +543,12 @@ class MomaTrajOptBatch:
         col = np.zeros(n, dtype=np.int32)
         _chk(self.L, self.L.topay_connect_collision(self.h, map_id, n, _ip(pn), _dp(car), _dp(qf), _dp(qt), _ip(col)))
         return col.astype(bool), pn
+
+    def share_maps(self, owner, first_map_id=0, n_maps=1):
+        """Use `owner`'s resident maps (same device) for these slots instead of a copy of the fields."""
+        self.L.topay_share_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _chk(self.L, self.L.topay_share_maps(self.h, owner.h, int(first_map_id), int(n_maps)))
+        self._map_owner = owner      # keeps the owner alive
 
     def mcrrt_params(self, **kw):
         p = McrrtParams()

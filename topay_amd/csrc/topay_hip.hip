@@ -22,6 +22,7 @@
 #include "topay_edt.h"
 #include "topay_front.h"
 #include "topay_mcrrt.h"
+#include "topay_yaml.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
 // One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
@@ -512,7 +513,18 @@ struct ClassDef {
   eval_kernel_t eval;
   int mwe = 0;   // the evaluation of topay_eval_mw.h (always for nw > 1); with one wave: in its compact LDS layout
 };
+// Latency mode (topay_set_latency_waves): every class up to 64 pieces on four waves per trajectory.  For a planning call of a
+// few candidates (BASELINE configs[1]) the device is empty anyway and the time of the call is the time of its longest
+// candidate; in a full batch the extra slots cost throughput (class_table() below).
+static int g_latency_waves = 0;
 static const ClassDef* class_table() {
+  static const ClassDef* lat = [] {
+    static ClassDef t[TOPAY_NBUCKET] = {
+        {10, 2, 4, k_solve2w4, k_eval2w4, 1}, {15, 2, 4, k_solve2w4, k_eval2w4, 1}, {21, 2, 4, k_solve2w4, k_eval2w4, 1}, {32, 2, 4, k_solve2w4, k_eval2w4, 1},
+        {42, 2, 4, k_solve2w4, k_eval2w4, 1}, {64, 2, 4, k_solve2w4, k_eval2w4, 1}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 1}};
+    return t;
+  }();
+  if (g_latency_waves == 4) return lat;
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
         {10, 1, 1, k_solve1, k_eval1}, {15, 2, 1, k_solve2, k_eval2}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
@@ -909,6 +921,34 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   return TOPAY_OK;
 }
 
+// Read-only map slots shared between the contexts of a device: `c` takes over the descriptors (device pointers) of the
+// slots `owner` holds, without a copy of the fields.  The batches in flight of a pipelined planner (one context each)
+// then keep one copy of the maps instead of one per context.
+extern "C" topay_status topay_share_maps(topay_ctx* c, topay_ctx* owner, int first_map_id, int n_maps) {
+  if (!c || !owner || c == owner || first_map_id < 0 || n_maps <= 0 || first_map_id + n_maps > TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
+  if (c->device != owner->device) { set_err("topay_share_maps: the contexts are on different devices"); return TOPAY_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  for (int m = first_map_id; m < first_map_id + n_maps; m++)
+    if (!owner->have_map[m]) return TOPAY_ERR_NO_MAP;
+  for (int m = first_map_id; m < first_map_id + n_maps; m++) {
+    c->map2d[m].release(); c->map3d[m].release(); c->map2d_inf[m].release(); c->map2d_crit[m].release();   // own copies of these slots, if any
+    c->hmaps[m] = owner->hmaps[m];
+    c->have_map[m] = 1;
+  }
+  for (size_t i = 0; i < c->map_arenas.size();) {   // arenas of own builds that only held these slots
+    topay_ctx::MapArena& a = c->map_arenas[i];
+    if (a.first >= first_map_id && a.first + a.n <= first_map_id + n_maps) {
+      a.buf.release();
+      c->map_arenas.erase(c->map_arenas.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
+  HIPCHK(memcpy_sync(c, (char*)c->dmaps.p + sizeof(DevMap) * first_map_id, &c->hmaps[first_map_id], sizeof(DevMap) * n_maps, hipMemcpyHostToDevice));
+  return TOPAY_OK;
+}
+
 static int bucket_of(int N) {
   // diagnostic: TOPAY_FORCE_CLASS=k sends every candidate that fits through launch class k (1-based) or a later one
   static const int force = [] { const char* f = getenv("TOPAY_FORCE_CLASS"); return f ? atoi(f) : 0; }();
@@ -973,6 +1013,18 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   if ((s = c->edt_tmp2.ensure(M * n3 * 8)) != TOPAY_OK) return s;
   // results: e3 | e2 | e2 inflate | e2 critical in a new arena (they stay there); the plain critical field is scratch
   // (a rebuild of the same range of slots -- a new episode's maps -- takes the arena of the previous build over)
+  // arenas of earlier builds whose slots this build overwrites completely are released (a caller that varies the slot
+  // ranges would otherwise accumulate full-size arenas until topay_destroy)
+  for (size_t i = 0; i < c->map_arenas.size();) {
+    topay_ctx::MapArena& a = c->map_arenas[i];
+    const bool same = a.first == first_map_id && a.n == n_maps;
+    if (!same && a.first >= first_map_id && a.first + a.n <= first_map_id + n_maps) {
+      a.buf.release();
+      c->map_arenas.erase(c->map_arenas.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
   topay_ctx::MapArena* ar = nullptr;
   for (auto& a : c->map_arenas)
     if (a.first == first_map_id && a.n == n_maps) ar = &a;
@@ -1363,7 +1415,10 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   const ClassDef* ct = class_table();
   double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    const double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
+    double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
+    // experiment knob: the smallest class's workgroups cannot take over anybody's queue, the others can take over its
+    static const double bias0 = [] { const char* e = getenv("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 1.0; }();
+    if (k == 0) slot_cost *= bias0;
     for (int b : c->cls[k]) wk[k] += slot_cost * std::pow((double)c->hN[b], 1.5);
     wt += wk[k];
   }
@@ -1906,6 +1961,27 @@ topay_status topay_connect_collision(topay_ctx* c, int map_id, int n_edges, cons
   HIPCHK(hipStreamSynchronize(c->stream));
   d_i.release();
   d_d.release();
+  return TOPAY_OK;
+}
+
+topay_status topay_set_latency_waves(int waves) {
+  if (waves != 0 && waves != 4) return TOPAY_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(g_registry_mutex);
+  for (topay_ctx* q : g_contexts)
+    if (q->pending) { set_err("topay_set_latency_waves: a solve is in flight"); return TOPAY_ERR_INVALID_ARG; }
+  g_latency_waves = waves;
+  return TOPAY_OK;
+}
+
+topay_status topay_params_from_yaml(const char* path_or_text, topay_params_t* params, char* ignored, int ignored_cap) {
+  if (!path_or_text || !params) return TOPAY_ERR_INVALID_ARG;
+  std::string ign, err;
+  const topay_status s = topay_yaml::apply_source(path_or_text, params, ign, err);
+  if (s != TOPAY_OK) { set_err("topay_params_from_yaml: " + err); return s; }
+  if (ignored && ignored_cap > 0) {
+    strncpy(ignored, ign.c_str(), (size_t)ignored_cap - 1);
+    ignored[ignored_cap - 1] = 0;
+  }
   return TOPAY_OK;
 }
 
