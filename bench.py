@@ -348,17 +348,6 @@ def main():
         ms1, _ = o1.last_kernel_ms()
         cfg1 = {"workload": "BASELINE configs[1]: 1 tables scenario x 64 candidates", "solve_ms": float(ms1),
                 "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
-        # the same call in latency mode (topay_set_latency_waves: four waves per candidate -- the device is empty anyway)
-        try:
-            api.set_latency_waves(4)
-            o1.set_init_traj(lens1, paths1)
-            o1.optimize()
-            o1.reset()
-            ok4 = o1.optimize()
-            ms4, _ = o1.last_kernel_ms()
-            cfg1["latency_mode_four_waves"] = {"solve_ms": float(ms4), "success_fraction": float(ok4.mean())}
-        finally:
-            api.set_latency_waves(0)
         o1.close()
         w1.close()
     simd_slots = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count

@@ -134,13 +134,6 @@ typedef struct topay_ctx topay_ctx;
 /* Fill `p` with the reference defaults (optimizer.yaml + MomaParam). */
 topay_status topay_default_params(topay_params_t* p);
 
-/* Latency mode, process-wide: waves = 4 solves every candidate of up to 64 pieces with four waves (a whole compute unit's
- * SIMDs) instead of the throughput configuration's one or two; 0 restores the default.  For a planner that optimises the
- * <= 8 candidates of ONE call at a time (planner.cpp:59, 829, 921-925) the device is empty anyway and the call takes as
- * long as its longest candidate.  Evaluations are bit-identical to the default's; the solver's sums are divided over four
- * times the threads, so converged values differ in the last bits.  Not while a solve is in flight. */
-topay_status topay_set_latency_waves(int waves);
-
 /* == MomaTrajOpt::init (src/planner/include/planner/moma_traj_opt.h:845-941) for a caller without a ROS parameter server:
  * the optimiser parameters from the reference's parameter file (src/planner/params/optimizer.yaml, under
  * `planner_node: moma_traj_opt:` or at top level).  path_or_text: a file name, or the YAML text itself.  Keys that are

@@ -119,21 +119,6 @@ def test_multiwave_solver_equals_oracle_in_device_order_on_cpu(cuboids_small):
     _capped_solve_vs_device_order(EMU_LIB, cuboids_small, [serpentine_path(34.0), serpentine_path(99.0)], 6, 4, 2)
 
 
-def test_latency_mode_solver_equals_oracle_in_device_order_on_cpu(cuboids_small):
-    """topay_set_latency_waves(4): the common candidates (4 and 10 pieces) on four waves -- the class table says so, and the
-    capped solves equal the oracle's solver logic over 256 threads bit for bit; the default comes back afterwards."""
-    cs = cuboids_small
-    L = api.load(EMU_LIB)
-    opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
-    try:
-        api.set_latency_waves(4, lib=L)
-        assert [opt.class_of(N)[0] for N in (3, 10, 21, 33, 64, 128)] == [4] * 6
-        _capped_solve_vs_device_order(EMU_LIB, cs, [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in (0, 3)], 6, 4, 2)
-    finally:
-        api.set_latency_waves(0, lib=L)
-    assert opt.class_of(10)[0] == 1
-
-
 @pytest.mark.gpu
 def test_multiwave_evaluation_is_order_identical_on_gpu(cuboids_small):
     cs = cuboids_small

@@ -257,13 +257,6 @@ def params_from_yaml(source, base=None, lib=None):
     return p, ignored
 
 
-def set_latency_waves(waves, lib=None):
-    """Process-wide latency mode (topay_set_latency_waves): 4 = every candidate up to 64 pieces on four waves, 0 = default."""
-    L = lib or load()
-    L.topay_set_latency_waves.argtypes = [C.c_int]
-    _chk(L, L.topay_set_latency_waves(int(waves)))
-
-
 def params_from_yaml_c(source, base=None, lib=None):
     """The library's own loader (topay_params_from_yaml, for C / C++ callers): same mapping as params_from_yaml."""
     L = lib or load()

@@ -513,18 +513,7 @@ struct ClassDef {
   eval_kernel_t eval;
   int mwe = 0;   // the evaluation of topay_eval_mw.h (always for nw > 1); with one wave: in its compact LDS layout
 };
-// Latency mode (topay_set_latency_waves): every class up to 64 pieces on four waves per trajectory.  For a planning call of a
-// few candidates (BASELINE configs[1]) the device is empty anyway and the time of the call is the time of its longest
-// candidate; in a full batch the extra slots cost throughput (class_table() below).
-static int g_latency_waves = 0;
 static const ClassDef* class_table() {
-  static const ClassDef* lat = [] {
-    static ClassDef t[TOPAY_NBUCKET] = {
-        {10, 2, 4, k_solve2w4, k_eval2w4, 1}, {15, 2, 4, k_solve2w4, k_eval2w4, 1}, {21, 2, 4, k_solve2w4, k_eval2w4, 1}, {32, 2, 4, k_solve2w4, k_eval2w4, 1},
-        {42, 2, 4, k_solve2w4, k_eval2w4, 1}, {64, 2, 4, k_solve2w4, k_eval2w4, 1}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 1}};
-    return t;
-  }();
-  if (g_latency_waves == 4) return lat;
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
         {10, 1, 1, k_solve1, k_eval1}, {15, 2, 1, k_solve2, k_eval2}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
@@ -1416,8 +1405,9 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
-    // experiment knob: the smallest class's workgroups cannot take over anybody's queue, the others can take over its
-    static const double bias0 = [] { const char* e = getenv("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 1.0; }();
+    // the smallest class's workgroups cannot take over anybody's queue, the others can take over its: it gets less than its share
+    // (measured, tools/r3_bias.sh, factor 1.0 / 0.9 / 0.8 / 0.7: serial step 1.00 / 0.99 / 0.98 / 0.97 s, pipelined 10.0-10.1k / 10.1k / 10.1k / 10.1k)
+    static const double bias0 = [] { const char* e = getenv("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 0.8; }();
     if (k == 0) slot_cost *= bias0;
     for (int b : c->cls[k]) wk[k] += slot_cost * std::pow((double)c->hN[b], 1.5);
     wt += wk[k];
@@ -1961,15 +1951,6 @@ topay_status topay_connect_collision(topay_ctx* c, int map_id, int n_edges, cons
   HIPCHK(hipStreamSynchronize(c->stream));
   d_i.release();
   d_d.release();
-  return TOPAY_OK;
-}
-
-topay_status topay_set_latency_waves(int waves) {
-  if (waves != 0 && waves != 4) return TOPAY_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(g_registry_mutex);
-  for (topay_ctx* q : g_contexts)
-    if (q->pending) { set_err("topay_set_latency_waves: a solve is in flight"); return TOPAY_ERR_INVALID_ARG; }
-  g_latency_waves = waves;
   return TOPAY_OK;
 }
 
