@@ -34,3 +34,31 @@ o2.build_esdf_fields(w1.origin, w1.res, w1.dims, w1.min_b, w1.max_b, w1.occ2d, N
 print("fields", [f.shape for f in o2.get_map_fields(0)[:4]])
 raw = np.array([[0.0, 0.0], [1.0, 0.2], [2.5, 1.0], [2.6, 3.0]])
 print("dense", np.asarray(o2.dense_path([raw], [0.3], [1.0])[0]).shape)
+# round 3: the joint-space search + Reeds-Shepp, several waves per trajectory, cancellation, parameter file, shared maps
+tb = wl.TablesBatch(2, 4, base_seed=31337, nthreads=2)
+o3 = api.MomaTrajOptBatch(params=p, lib_path=LIB)
+slot = {s: k for k, s in enumerate(tb.scenarios)}
+for s_ in tb.scenarios:
+    ww = tb.world(s_)
+    o3.set_map(ww.origin, ww.res, ww.dims, ww.min_b, ww.max_b, ww.esdf2d, ww.esdf3d, slot[s_])
+offs = np.concatenate([[0], np.cumsum(tb.lens)])
+car = np.c_[tb.paths[:, :3], tb.dts]
+mid = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+wbs, mst, _ = o3.mcrrt_plan(tb.lens, car, tb.paths[offs[:-1]], tb.paths[offs[1:] - 1], o3.mcrrt_params(seed=3, max_iter=150, node_cap=64), map_ids=mid)
+print("mcrrt", mst[:, :3].tolist())
+print("rs", o3.reeds_shepp(rng.uniform(-1, 1, (50, 3)), rng.uniform(-1, 1, (50, 3)), rng.uniform(0, 1, 50))[0][:3])
+o4 = api.MomaTrajOptBatch(params=p, lib_path=LIB)
+o4.share_maps(o3, 0, len(tb.scenarios))
+o4.set_init_traj(tb.lens, tb.paths, map_ids=mid)
+o4.set_groups(tb.scen, 200)
+o4.optimize()
+print("cancel", o4.interrupted().tolist())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import serpentine_path
+lp = [serpentine_path(34.0), serpentine_path(99.0)]
+p2 = api.default_params(api.load(LIB)); p2.s1_lbfgs.max_iterations = 3; p2.s2_lbfgs.max_iterations = 3; p2.alm_max_outer = 1
+o5 = api.MomaTrajOptBatch(params=p2, lib_path=LIB)
+o5.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, 0)
+o5.optimizeTraj(np.array([len(q) for q in lp], dtype=np.int32), np.concatenate(lp))
+print("multi-wave", o5.n_pieces().tolist(), o5.stats()[:, :3].tolist())
+print("yaml", api.params_from_yaml_c("second_stage:\n  time_weight: 51.0\n  lbfgs: {past: 4}\n", lib=api.load(LIB))[0].s2_time_weight)

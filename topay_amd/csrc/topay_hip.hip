@@ -1406,7 +1406,8 @@ static void compute_shares(topay_ctx* c, int slots, int* share) {
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
     double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
     // the smallest class's workgroups cannot take over anybody's queue, the others can take over its: it gets less than its share
-    // (measured, tools/r3_bias.sh, factor 1.0 / 0.9 / 0.8 / 0.7: serial step 1.00 / 0.99 / 0.98 / 0.97 s, pipelined 10.0-10.1k / 10.1k / 10.1k / 10.1k)
+    // (measured, tools/r3_bias.sh, factor 1.0 / 0.9 / 0.8 / 0.7: serial step 1.00 / 0.99 / 0.98 / 0.97 s, pipelined 10.0-10.1k / 10.1k / 10.1k / 10.1k;
+    // further per-class factors from the launches' measured durations, tools/r3_mult.sh: nothing, 9.9-10.1k)
     static const double bias0 = [] { const char* e = getenv("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 0.8; }();
     if (k == 0) slot_cost *= bias0;
     for (int b : c->cls[k]) wk[k] += slot_cost * std::pow((double)c->hN[b], 1.5);
