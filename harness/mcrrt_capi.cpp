@@ -2,6 +2,7 @@
 // built with -ffp-contract=off: the search compares costs computed with a*b+c expressions, and a fused multiply-add
 // on the host would differ from the device (built with contraction off) in the last bit.
 #include "mcrrt.hpp"
+#include "jps.hpp"
 
 using namespace topay_wl;
 
@@ -55,6 +56,18 @@ double wl_rs_path(double rho, const double* from, const double* to, int* type, d
   return rho * p.total;
 }
 void wl_rs_interpolate(double rho, const double* from, const double* to, double t, double* out) { ReedsShepp(rho).interpolate(from, to, t, out); }
+
+// GraphSearch::plan2dJPS on `world`'s 2-D distance field: returns the number of path points (0 = no path), writes at most
+// cap of them; stats[0] = expanded nodes, stats[1] = jump points of the raw path (before the zigzag cut).
+int wl_plan2d_jps(void* world, const double* start, const double* end, double threshold, int cap, double* out_xy, int* stats) {
+  const World& w = *(const World*)world;
+  GraphSearch gs(w.gm, threshold);
+  auto path = gs.plan2dJPS(start, end, threshold);
+  stats[0] = gs.expand_iteration;
+  stats[1] = (int)gs.path_.size();
+  for (size_t i = 0; i < path.size() && (int)i < cap; i++) { out_xy[2 * i] = path[i][0]; out_xy[2 * i + 1] = path[i][1]; }
+  return (int)path.size();
+}
 
 double wl_mcrrt_u01(unsigned long long seed, unsigned long long inst, unsigned long long iter, unsigned long long slot) {
   return mcrrt_u01(seed, inst, iter, slot);

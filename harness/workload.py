@@ -334,6 +334,19 @@ def mcrrt_plan(world, start, end, car_path, params=None, inst=0, track_slack=Fal
     return out
 
 
+def plan2d_jps(world, start_xy, end_xy, threshold=0.5, cap=4096):
+    """CPU restatement of GraphSearch::plan2dJPS (graph_search.cpp:53-117) -> ([m, 2] path, empty when none; (expanded nodes,
+    jump points of the raw path))."""
+    L = mlib()
+    L.wl_plan2d_jps.argtypes = [C.c_void_p, c_dp, c_dp, C.c_double, C.c_int, c_dp, c_ip]
+    a = np.ascontiguousarray(start_xy, dtype=np.float64)
+    b = np.ascontiguousarray(end_xy, dtype=np.float64)
+    out = np.zeros((cap, 2))
+    st = np.zeros(2, dtype=np.int32)
+    n = L.wl_plan2d_jps(world.h, _dp(a), _dp(b), float(threshold), cap, _dp(out), st.ctypes.data_as(c_ip))
+    return out[:min(n, cap)].copy(), (int(st[0]), int(st[1]))
+
+
 def rs_path(from_pose, to_pose, rho=1.0e-2):
     """ompl::base::ReedsSheppStateSpace(rho).reedsShepp(from, to) restated: (word 0..17, five signed lengths, distance)."""
     L = mlib()

@@ -288,6 +288,18 @@ topay_status topay_connect_check_num(int n_edges, const double* rs_distance, con
 topay_status topay_connect_collision(topay_ctx* ctx, int map_id, int n_edges, const int* piece_num, const double* car_poses,
                                      const double* q_from, const double* q_to, int* collide);
 
+/* == GraphSearch::plan2dJPS (src/planner/src/graph_search.cpp:53-117, with plan / getJpsSucc / jump / hasForced 178-475 and the
+ * JPS2DNeib neighbour rules 583-669): the planner's direct chassis path (planner.cpp:816: threshold = chassis radius + 0.1)
+ * for n (start, goal) pairs -- jump-point search on the 2-D distance field of each pair's map slot, then the zigzag cut
+ * with GridMap::isLineCollisionGrid2d (grid_map.h:565-610).  out_len[p] = points of path p (0: no path; counts beyond
+ * cap_points are reported, not written), out_xy + p * cap_points * 2 = its points, first = start, last = goal: the raw
+ * path topay_dense_path takes.  stats (n x 2, optional): expanded nodes, jump points before the cut.  The open list
+ * follows boost::heap::d_ary_heap<arity<2>> with the reference's compare_state (graph_search.h:20-38; boost is not part of
+ * the reference's sources, its sift rules are restated), which is what decides between equal-cost paths.  One thread per
+ * search; the search state (21 bytes per map cell and search) is allocated for the call. */
+topay_status topay_plan2d_jps(topay_ctx* ctx, int n, const int* map_ids /* n, NULL = slot 0 */, const double* start_xy /* n x 2 */,
+                              const double* end_xy /* n x 2 */, double threshold, int cap_points, int* out_len, double* out_xy, int* stats);
+
 /* == MCRRTs::plan (src/planner/src/mcrrts.cpp:5-231; steer / rewire 336-400; the inline members of
  * src/planner/include/planner/mcrrts.h:153-348), the layered bidirectional search over the arm joints along a fixed chassis
  * path that produces optimizeTraj's init path -- n instances (candidate chassis paths) per call, one wavefront each.

@@ -208,3 +208,92 @@ def test_front_end_feeds_the_solver_on_gpu():
     print(f"{len(keep)} of {len(sel)} searches found a path; the solver converged on {ok.mean():.3f} of them")
     assert ok.mean() > 0.8
     tb.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the 2-D jump-point search (GraphSearch::plan2dJPS, graph_search.cpp:53-117): topay_plan2d_jps
+# ---------------------------------------------------------------------------------------------------------------------
+def _jps_compare(opt, tb, threshold=0.5):
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    for s_ in tb.scenarios:
+        set_map(opt, tb.world(s_), map_id=slot[s_])
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    first = [int(np.nonzero(tb.scen == s_)[0][0]) for s_ in tb.scenarios]       # one (start, goal) pair per scenario
+    st = np.array([tb.paths[offs[b], :2] for b in first])
+    en = np.array([tb.paths[offs[b + 1] - 1, :2] for b in first])
+    mid = np.array([slot[tb.scen[b]] for b in first], dtype=np.int32)
+    paths, stats, ln = opt.plan2d_jps(st, en, threshold, map_ids=mid)
+    n_path = 0
+    for k, b in enumerate(first):
+        w = tb.world(int(tb.scen[b]))
+        ref, rs = wl.plan2d_jps(w, st[k], en[k], threshold)
+        assert tuple(stats[k]) == rs and ln[k] == len(ref), (k, stats[k], rs, ln[k], len(ref))
+        assert paths[k].shape == ref.shape and (paths[k] == ref).all(), k           # the same cells, the same positions, bit for bit
+        if len(ref):
+            n_path += 1
+            assert (ref[0] == st[k]).all() and (ref[-1] == en[k]).all()
+            # a path of the planner's threshold: every point but the exact start / goal is the centre of a free cell
+            idx = np.floor((ref[1:-1] - w.origin[:2]) / w.res).astype(int)
+            assert (w.esdf2d.reshape(w.dims[0], w.dims[1])[idx[:, 0], idx[:, 1]] >= threshold).all()
+    return n_path, stats
+
+
+def test_plan2d_jps_kernel_sources_on_cpu():
+    """The search kernel in the lane emulator against the restatement: 16 tables scenarios -- expanded nodes, jump points and
+    the returned path bit for bit; plus no path (goal inside an obstacle), start and goal in one cell, a point outside the map."""
+    tb = wl.TablesBatch(16, 1, base_seed=31337, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0, lib_path=EMU_LIB)
+    n_path, stats = _jps_compare(opt, tb)
+    assert n_path == 16 and stats[:, 0].max() > 1000
+    w = tb.world(int(tb.scen[0]))
+    e2 = w.esdf2d.reshape(w.dims[0], w.dims[1])
+    ox, oy = np.unravel_index(np.argmin(e2), e2.shape)                           # deepest inside an obstacle
+    blocked = np.array([(ox + 0.5) * w.res + w.origin[0], (oy + 0.5) * w.res + w.origin[1]])
+    s0 = tb.paths[0, :2]
+    cases_s = np.array([s0, s0, s0])
+    cases_e = np.array([blocked, s0 + 1e-3, [w.origin[0] - 1.0, s0[1]]])
+    paths, stats, ln = opt.plan2d_jps(cases_s, cases_e, 0.5, map_ids=np.zeros(3, dtype=np.int32))
+    for k in range(3):
+        ref, rs = wl.plan2d_jps(w, cases_s[k], cases_e[k], 0.5)
+        assert ln[k] == len(ref) and (paths[k] == ref).all() and tuple(stats[k]) == rs, (k, ln[k], len(ref), stats[k], rs)
+    assert ln[0] == 0 and ln[2] == 0 and ln[1] == 1
+    tb.close()
+
+
+@pytest.mark.gpu
+def test_plan2d_jps_on_gpu_matches_restatement():
+    tb = wl.TablesBatch(256, 1, base_seed=99, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    n_path, stats = _jps_compare(opt, tb)
+    print(f"{len(tb.scenarios)} searches: {n_path} paths, identical to the restatement; expanded nodes mean {stats[:, 0].mean():.0f}, max {stats[:, 0].max()}")
+    assert n_path == len(tb.scenarios)
+    tb.close()
+
+
+@pytest.mark.gpu
+def test_front_end_chain_on_gpu():
+    """start / goal -> topay_plan2d_jps -> topay_dense_path -> topay_mcrrt_plan -> topay_set_init_traj -> topay_optimize: the
+    planner's path from a scenario to a trajectory (planner.cpp:816-885) with every step on the device."""
+    tb = wl.TablesBatch(64, 1, base_seed=2024, nthreads=8)
+    opt = api.MomaTrajOptBatch(device=0)
+    slot = {s: k for k, s in enumerate(tb.scenarios)}
+    for s_ in tb.scenarios:
+        set_map(opt, tb.world(s_), map_id=slot[s_])
+    offs = np.concatenate([[0], np.cumsum(tb.lens)])
+    start = tb.paths[offs[:-1]]
+    goal = tb.paths[offs[1:] - 1]
+    mid = np.array([slot[s] for s in tb.scen], dtype=np.int32)
+    raw, _, ln = opt.plan2d_jps(start[:, :2], goal[:, :2], 0.5, map_ids=mid)
+    assert (ln >= 2).all()
+    dense, n_dense = opt.dense_path(raw, start[:, 2], goal[:, 2])
+    lens = np.array([len(d) for d in dense], dtype=np.int32)
+    end = goal.copy()
+    end[:, 2] = [d[-1, 2] for d in dense]           # (the dense path's last yaw is the goal's, normalised to its predecessor)
+    wbs, mst, _ = opt.mcrrt_plan(lens, np.concatenate(dense), start, end, opt.mcrrt_params(seed=5), map_ids=mid)
+    keep = [k for k in range(len(lens)) if mst[k, 0] == 1]
+    assert len(keep) > 0.6 * len(lens)
+    opt.set_init_traj(np.array([len(wbs[k]) for k in keep], dtype=np.int32), np.concatenate([wbs[k] for k in keep]), map_ids=mid[keep])
+    ok = opt.optimize()
+    print(f"{len(lens)} scenarios: {len(keep)} whole-body init paths, {int(ok.sum())} converged trajectories")
+    assert ok.mean() > 0.8
+    tb.close()

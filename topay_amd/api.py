@@ -543,6 +543,18 @@ class MomaTrajOptBatch:
         _chk(self.L, self.L.topay_share_maps(self.h, owner.h, int(first_map_id), int(n_maps)))
         self._map_owner = owner      # keeps the owner alive
 
+    def plan2d_jps(self, start_xy, end_xy, threshold=0.5, map_ids=None, cap=512):
+        """GraphSearch::plan2dJPS for a batch of (start, goal) pairs -> (list of [m, 2] paths (empty: none), stats [n, 2])."""
+        a = np.ascontiguousarray(start_xy, dtype=np.float64).reshape(-1, 2)
+        b = np.ascontiguousarray(end_xy, dtype=np.float64).reshape(-1, 2)
+        n = len(a)
+        mid = None if map_ids is None else np.ascontiguousarray(map_ids, dtype=np.int32)
+        ln, st, out = np.zeros(n, dtype=np.int32), np.zeros((n, 2), dtype=np.int32), np.zeros((n, cap, 2))
+        self.L.topay_plan2d_jps.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, C.c_double, C.c_int, c_ip, c_dp, c_ip]
+        _chk(self.L, self.L.topay_plan2d_jps(self.h, n, None if mid is None else _ip(mid), _dp(a), _dp(b), float(threshold), int(cap), _ip(ln), _dp(out),
+                                             _ip(st)))
+        return [out[p, :min(ln[p], cap)].copy() for p in range(n)], st, ln
+
     def mcrrt_params(self, **kw):
         p = McrrtParams()
         self.L.topay_mcrrt_default_params(C.byref(p))

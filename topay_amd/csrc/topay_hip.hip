@@ -22,6 +22,7 @@
 #include "topay_edt.h"
 #include "topay_front.h"
 #include "topay_mcrrt.h"
+#include "topay_jps.h"
 #include "topay_yaml.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
@@ -1964,6 +1965,61 @@ topay_status topay_params_from_yaml(const char* path_or_text, topay_params_t* pa
     strncpy(ignored, ign.c_str(), (size_t)ignored_cap - 1);
     ignored[ignored_cap - 1] = 0;
   }
+  return TOPAY_OK;
+}
+
+topay_status topay_plan2d_jps(topay_ctx* c, int n, const int* map_ids, const double* start_xy, const double* end_xy, double threshold,
+                              int cap_points, int* out_len, double* out_xy, int* stats) {
+  if (!c || n < 0 || cap_points < 2 || (n > 0 && (!start_xy || !end_xy || !out_len || !out_xy))) return TOPAY_ERR_INVALID_ARG;
+  if (n == 0) return TOPAY_OK;
+  std::vector<int> mid((size_t)n, 0);
+  long long ncell = 0;
+  for (int p = 0; p < n; p++) {
+    mid[p] = map_ids ? map_ids[p] : 0;
+    if (mid[p] < 0 || mid[p] >= TOPAY_MAX_MAPS) return TOPAY_ERR_INVALID_ARG;
+    if (!c->have_map[mid[p]]) return TOPAY_ERR_NO_MAP;
+    ncell = std::max(ncell, (long long)c->hmaps[mid[p]].dims[0] * c->hmaps[mid[p]].dims[1]);
+  }
+  HIPCHK(hipSetDevice(c->device));
+  // search state per instance: g (8) + parent, heap position, heap (3 x 4) + flags (1) bytes per cell; searches run in
+  // chunks of at most 2 GB of it
+  const size_t per = (size_t)ncell * 21;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)2 << 30) / std::max<size_t>(per, 1)));
+  DevBuf ws, io;
+  topay_status s;
+  if ((s = ws.ensure((size_t)chunk * per + 64)) != TOPAY_OK) return s;
+  const size_t io_d = (size_t)n * 4 + (size_t)n * cap_points * 2, io_i = (size_t)n * 4;
+  if ((s = io.ensure(io_d * 8 + io_i * 4)) != TOPAY_OK) { ws.release(); return s; }
+  double* d_start = io.as<double>();
+  double* d_end = d_start + 2 * (size_t)n;
+  double* d_out = d_end + 2 * (size_t)n;
+  int* d_mid = (int*)(d_out + (size_t)n * cap_points * 2);
+  int* d_len = d_mid + n;
+  int* d_stats = d_len + n;
+  HIPCHK(hipMemcpyAsync(d_start, start_xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_end, end_xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_mid, mid.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  topay::JpsBatch B;
+  B.cap = cap_points; B.ncell_max = ncell; B.map_id = d_mid; B.start = d_start; B.end = d_end; B.threshold = threshold;
+  B.g = ws.as<double>();
+  B.parent = (int*)(B.g + (size_t)chunk * ncell);
+  B.hpos = B.parent + (size_t)chunk * ncell;
+  B.heap = B.hpos + (size_t)chunk * ncell;
+  B.flag = (unsigned char*)(B.heap + (size_t)chunk * ncell);
+  B.out_len = d_len; B.out_xy = d_out; B.stats = d_stats;
+  for (int i0 = 0; i0 < n; i0 += chunk) {
+    B.inst0 = i0;
+    B.n = std::min(chunk, n - i0);
+    HIPCHK(hipMemsetAsync(B.flag, 0, (size_t)B.n * ncell, c->stream));
+    hipLaunchKernelGGL(topay::k_jps, dim3((unsigned)((B.n + 63) / 64)), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, B);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(out_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_xy, d_out, (size_t)n * cap_points * 16, hipMemcpyDeviceToHost, c->stream));
+  if (stats) HIPCHK(hipMemcpyAsync(stats, d_stats, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ws.release();
+  io.release();
   return TOPAY_OK;
 }
 
