@@ -806,7 +806,11 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   // two contexts then use ten of the sixteen hardware queues the library asks for, and no operation of one context
   // waits for another context's solve.
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    if (k == topay_ctx::NBUCKET - 1) c->bstream[k] = c->stream;
+    // (the two longest classes start on the main stream: streams are hardware queues, and 3 contexts x 7 streams beside
+    // torch's and RCCL's exceed the 24 the library asks for -- a gather that shares a queue with a persistent solve
+    // launch waits a whole solve, 9.1k instead of 10.0k trajectories/s through the RCCL path.  The N <= 64 class gets a
+    // stream of its own the first time a batch also holds candidates of more than 64 pieces, launch_classes.)
+    if (k >= topay_ctx::NBUCKET - 2) c->bstream[k] = c->stream;
     else HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->bevent[k]));
   }
@@ -1509,6 +1513,8 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
     off += nk;
     const size_t lds = class_lds_bytes(ct[k], nm);
     const int compact = class_compact(ct[k], nm);
+    if (k == topay_ctx::NBUCKET - 2 && !c->cls[topay_ctx::NBUCKET - 1].empty() && c->bstream[k] == c->stream)
+      HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));   // both long classes in one batch: they must not serialise
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
     if constexpr (EVAL) hipLaunchKernelGGL(ct[k].eval, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm, compact);
