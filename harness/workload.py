@@ -330,7 +330,9 @@ def mcrrt_plan(world, start, end, car_path, params=None, inst=0, track_slack=Fal
                         stats.ctypes.data_as(c_ip), C.byref(cmax), C.byref(slack), prm.node_cap, nodes)
     out = dict(status=int(s), wb_path=wb[:wl_.value].copy(), stats=stats, c_max=cmax.value, min_slack=slack.value, nodes=None)
     if want_nodes:
-        out["nodes"] = np.ctypeslib.as_array(nodes)[:stats[1]].copy() if stats[1] > 0 else np.zeros(0, dtype=[("layer", "i4")])
+        rec = np.dtype([("layer", "<i4"), ("state", "<i4"), ("parent", "<i4"), ("pad", "<i4"), ("cost", "<f8"), ("q", "<f8", (7,))])
+        assert rec.itemsize == C.sizeof(McrrtNodeRec)
+        out["nodes"] = np.frombuffer(nodes, dtype=rec, count=prm.node_cap)[:stats[1]].copy()
     return out
 
 
