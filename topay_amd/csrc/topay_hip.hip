@@ -821,6 +821,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->simd_slots = 4 * prop.multiProcessorCount;   // one wave per SIMD (TOPAY_WAVES_PER_EU = 1), four SIMDs per CU
+    if (const char* sp = getenv("TOPAY_SLOTS_PER_SIMD")) c->simd_slots *= std::max(1, atoi(sp));   // (experiments with builds of TOPAY_WAVES_PER_EU > 1)
     // A few slots are left to everything that is not a solve: the init kernel, the feasibility gate and the result
     // gather of the OTHER batches in flight, the runtime's copy kernels, a collective.  Resident solver waves own their
     // SIMD's whole register file, so on a device they fill completely such a kernel waits until workgroups exit.
