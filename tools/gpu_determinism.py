@@ -6,7 +6,8 @@ from topay_amd import api
 S = int(os.environ.get("S", "256"))
 w2, lens2, paths2, scen2 = wl.cuboids_batch(S, 8)
 res = {}
-for name, lib in (("w2a", None), ("w2b", None), ("w3", "topay_amd/lib/libtopay_hip_w3.so")):
+VARIANT = os.environ.get("TOPAY_VARIANT_LIB")   # optional second build (e.g. another optimisation level) to compare with
+for name, lib in (("w2a", None), ("w2b", None)) + ((("w3", VARIANT),) if VARIANT else ()):
     gpu = api.MomaTrajOptBatch(device=0, lib_path=lib)
     gpu.set_map(w2.origin, w2.res, w2.dims, w2.min_b, w2.max_b, w2.esdf2d, w2.esdf3d)
     gpu.set_init_traj(lens2, paths2)
@@ -14,13 +15,15 @@ for name, lib in (("w2a", None), ("w2b", None), ("w3", "topay_amd/lib/libtopay_h
     res[name] = (ok.copy(), gpu.traj_cost.copy(), gpu.stats().copy())
     print(name, "succ", ok.mean(), "evals", res[name][2][:, 2].sum() + res[name][2][:, 5].sum(), flush=True)
     gpu.close()
-for a, b in (("w2a", "w2b"), ("w2a", "w3")):
+for a, b in (("w2a", "w2b"),) + ((("w2a", "w3"),) if VARIANT else ()):
     same = (res[a][1] == res[b][1]) | (np.isnan(res[a][1]) & np.isnan(res[b][1]))
     seq = (res[a][2] == res[b][2]).all(axis=1)
     print(a, "vs", b, ": identical cost", same.mean(), "identical stats", seq.mean(), "first mismatches", np.nonzero(~same)[0][:10])
     bad = np.nonzero(~same)[0]
     for i in bad[:5]:
         print("   traj", i, "N", None, "stats", res[a][2][i], "|", res[b][2][i], "cost", res[a][1][i], res[b][1][i])
+if not VARIANT:
+    sys.exit(0)
 a, b = "w2a", "w3"
 same = (res[a][1] == res[b][1]) | (np.isnan(res[a][1]) & np.isnan(res[b][1]))
 seq = (res[a][2] == res[b][2]).all(axis=1)
