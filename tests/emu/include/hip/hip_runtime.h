@@ -245,9 +245,17 @@ inline int __all(int pred) {
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hip_emu::exchange(v, (hip_emu::S().cur & ~63) + lane); }
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  (void)bank_mask; (void)bound_ctrl;
   const int me = hip_emu::S().cur, l = me & 15, base = me & ~15;
   int from;
+  if (ctrl == 0x142 || ctrl == 0x143) {   // row_bcast15 / row_bcast31: lane 15 of the previous row / lane 31 into rows 2-3
+    const int row = (me >> 4) & 3;
+    const bool take = ((row_mask >> row) & 1) && (ctrl == 0x142 ? row >= 1 : row >= 2);
+    const int src_lane = ctrl == 0x142 ? (row >= 1 ? base - 1 : me) : (me & ~63) + 31;
+    const int got = hip_emu::exchange(src, src_lane);
+    return take ? got : old;
+  }
+  (void)old; (void)row_mask;
   switch (ctrl) {
     case 0xB1: from = base + (l ^ 1); break;                     // quad_perm [1,0,3,2]
     case 0x4E: from = base + (l ^ 2); break;                     // quad_perm [2,3,0,1]

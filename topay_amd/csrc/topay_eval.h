@@ -63,13 +63,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+// rows of 16 lanes outside ROWMASK receive 0.0 (the caller adds the result)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64_rows(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// 64-lane sum: a butterfly inside every row of 16 (every lane of row k then holds r_k), then across the rows:
+// (r0 + r1) + (r2 + r3), in lane 63.  The sum is 20 instructions of VALU issue -- f64 has no DPP operand form, every
+// level is two 32-bit DPP moves and an add -- and that, not the latency of the chain, is what a reduction costs
+// (DESIGN.md section 9); the cross-row levels replace four lane reads and three adds of rounds 1-2, same bits (the
+// operands of every addition are the same, in the other order).
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]   : lane ^ 1
   v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]   : lane ^ 2
   v += dpp_f64<0x141>(v);  // row_half_mirror       : quad q <-> quad q^1
   v += dpp_f64<0x140>(v);  // row_mirror            : half h <-> half h^1
-  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-  return (r0 + r1) + (r2 + r3);
+  v += dpp_f64_rows<0x142, 0xA>(v);   // row_bcast15: rows 1 and 3 += lane 15 of the row before  -> r1 + r0, r3 + r2
+  v += dpp_f64_rows<0x143, 0xC>(v);   // row_bcast31: rows 2 and 3 += lane 31                    -> (r3 + r2) + (r1 + r0)
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_max(double v) {
   double o;
