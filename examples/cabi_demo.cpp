@@ -1,8 +1,10 @@
 // Minimal C++ caller of the C-ABI (include/topay.h): what the reference-side adapter of INTEGRATION.md does, without
 // Eigen/ROS.  An obstacle-free 20 x 20 x 1.6 m map (distance fields built on the device from empty occupancy grids)
 // and two straight-line candidates; prints success, cost, pieces, feasibility and the end point of each, then the
-// scenario's record and its all-gather over RCCL (the multi-GPU exchange, world size 1).
+// scenario's record and its all-gather over RCCL (the multi-GPU exchange, world size 1), then the front-end chain
+// start / goal -> 2-D path -> dense path -> joint-space search -> trajectory around a wall.
 //   g++ -std=c++17 -Iinclude examples/cabi_demo.cpp -o /tmp/cabi_demo topay_amd/lib/libtopay_hip.so -Wl,-rpath,$PWD/topay_amd/lib
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -92,6 +94,54 @@ int main() {
     CHECK(topay_comm_destroy(ctx));
   } else {
     std::printf("record gather skipped: %s\n", topay_last_error());
+  }
+  // The planner's front-end in front of the solve (planner.cpp:816-885), every step on the device: a wall across the map with
+  // a gap, the direct 2-D path around it (GraphSearch::plan2dJPS), its dense path (getDensePath), the layered joint-space
+  // search along it (MCRRTs::plan), and the result as the init path of optimizeTraj.
+  {
+    std::fill(occ2.begin(), occ2.end(), 0);
+    std::fill(occ3.begin(), occ3.end(), 0);
+    for (int y = 0; y < ny; y++) {
+      if (y >= 150 && y < 170) continue;   // the gap: y in [5, 7) m
+      for (int x = 98; x < 102; x++) {     // the wall: x in [-0.2, 0.2) m
+        occ2[(size_t)x * ny + y] = 1;
+        for (int z = 0; z < nz; z++) occ3[((size_t)x * ny + y) * nz + z] = 1;
+      }
+    }
+    CHECK(topay_build_esdf(ctx, 1, &d, occ2.data(), occ3.data()));
+    const int map1 = 1;
+    double start[10] = {-4.0, -3.0, 0.3, 0.0, 0.6, 0.0, 1.2, 0.0, 0.6, 0.0}, end[10] = {4.0, -2.0, -0.5, 0.4, 0.3, -0.2, 1.0, 0.3, 0.8, 0.5};
+    const int cap = 256;
+    int jps_len = 0, jps_stats[2];
+    std::vector<double> jps_xy((size_t)cap * 2);
+    CHECK(topay_plan2d_jps(ctx, 1, &map1, start, end, p.chassis_colli_radius + 0.1, cap, &jps_len, jps_xy.data(), jps_stats));
+    int dense_len = 0;
+    std::vector<double> dense((size_t)cap * 4);
+    if (jps_len >= 2 && jps_len <= cap)
+      CHECK(topay_dense_path(ctx, 1, &jps_len, jps_xy.data(), 1.414, &start[2], &end[2], p.max_v, p.max_w, cap, &dense_len, dense.data()));
+    int wb_len = 0, mstats[8] = {0};
+    std::vector<double> wb((size_t)cap * 10);
+    if (dense_len >= 2 && dense_len <= cap) {
+      end[2] = dense[4 * (dense_len - 1) + 2];   // the dense path's last yaw: the goal's, normalised to its predecessor
+      topay_mcrrt_params_t mc;
+      topay_mcrrt_default_params(&mc);
+      CHECK(topay_mcrrt_plan(ctx, 1, &map1, &dense_len, dense.data(), start, end, &mc, 0, cap, &wb_len, wb.data(), mstats, nullptr));
+    }
+    std::printf("front-end: JPS %d points (%d nodes expanded), dense path %d poses, joint search status %d (%d nodes, %d iterations), %d states\n",
+                jps_len, jps_stats[0], dense_len, mstats[0], mstats[1], mstats[2], wb_len);
+    if (wb_len >= 2) {
+      CHECK(topay_set_init_traj(ctx, 1, &wb_len, wb.data(), nullptr, nullptr, &map1));
+      CHECK(topay_optimize(ctx));
+      int ok1 = 0, np1 = 0, feas1 = 0;
+      double c1 = 0.0, t1 = 0.0;
+      CHECK(topay_get_batch(ctx, &ok1, &c1, &np1));
+      CHECK(topay_check_feasible(ctx, &feas1));
+      CHECK(topay_get_total_durations(ctx, &t1));
+      std::printf("front-end: trajectory success %d pieces %d duration %.3f s feasible %d\n", ok1, np1, t1, feas1);
+      if (!ok1) bad++;
+    } else {
+      bad++;
+    }
   }
   topay_destroy(ctx);
   return bad ? 2 : 0;

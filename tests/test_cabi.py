@@ -102,6 +102,9 @@ def test_cpp_caller_runs_on_the_device(tmp_path):
     assert len(lines) == 2 and all("success 1" in ln for ln in lines)
     # the multi-GPU exchange through the C-ABI (ncclAllGather called by the library, world size 1)
     assert "record gather over RCCL (world 1): ok" in r.stdout, r.stdout + r.stderr
+    # the front-end chain through the C-ABI: 2-D path around the wall, dense path, joint-space search, trajectory
+    fe = [ln for ln in r.stdout.splitlines() if ln.startswith("front-end:")]
+    assert len(fe) == 2 and "joint search status 1" in fe[0] and "trajectory success 1" in fe[1], r.stdout
 
 
 def test_header_is_plain_c99():
