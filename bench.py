@@ -399,7 +399,7 @@ def main():
                          + ("; init paths from the device's MCRRTs::plan (--front-end)" if front_end else "")),
             "front_end": front_end,
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
-            "parallelism": f"scenario-sharded x{world}, one wavefront per trajectory, {depth} batches in flight per GPU",
+            "parallelism": f"scenario-sharded x{world}, one workgroup (1, 2 or 4 wavefronts) per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "max_pieces": int(n_pieces.max()),
             "pieces_over_32": int((n_pieces > 32).sum()),
             # candidates the device did not solve (more pieces than the build supports): none may hide in `value`
