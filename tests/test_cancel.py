@@ -68,6 +68,26 @@ def test_cancellation_rule_on_cpu(cuboids_small):
     _check_rule(EMU_LIB, cs["world"], cs["lens"], cs["paths"], p, groups)
 
 
+def test_cancellation_rule_with_a_two_wave_candidate_on_cpu(cuboids_small):
+    """The same rule when one candidate of the call runs on two waves (33 pieces: the verdict of the poll travels to the
+    second wave through LDS)."""
+    from conftest import serpentine_path
+
+    cs = cuboids_small
+    p = api.default_params(api.load(EMU_LIB))
+    p.s1_lbfgs.max_iterations = 40
+    p.s2_lbfgs.max_iterations = 25
+    p.alm_max_outer = 2
+    p.alm_tolerance = 10.0
+    long_ = serpentine_path(34.0)
+    sel = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in (0, 3)] + [long_]
+    lens = np.array([len(q) for q in sel], dtype=np.int32)
+    paths = np.concatenate(sel)
+    groups = np.array([0, 0, 0], dtype=np.int32)
+    base, clock, acc = _check_rule(EMU_LIB, cs["world"], lens, paths, p, groups)
+    assert base["N"][2] == 33
+
+
 def test_oracle_rule_known_answers():
     g = np.array([0, 0, 0, 1, 1, -1, 2])
     clock = np.array([100, 350, 351, 50, 5000, 10 ** 9, 70])
