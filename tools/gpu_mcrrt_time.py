@@ -33,3 +33,18 @@ for b in range(k):
     wl.mcrrt_plan(tb.world(int(tb.scen[b])), start[b], end[b], car[offs[b]:offs[b + 1]], wl.McrrtParams(seed=42), inst=b, want_nodes=False)
 dt = time.perf_counter() - t0
 print(f"CPU restatement, one thread: {k} searches in {dt:.2f} s = {k / dt:.0f} searches/s")
+# the 2-D jump-point search (one thread per search): one (start, goal) pair per scenario
+first = np.array([int(np.nonzero(tb.scen == s_)[0][0]) for s_ in tb.scenarios])
+st2, en2 = tb.paths[offs[first], :2], tb.paths[offs[first + 1] - 1, :2]
+mid2 = np.array([slot[tb.scen[b]] for b in first], dtype=np.int32)
+for rep in range(2):
+    t0 = time.perf_counter()
+    jp, jst, jln = opt.plan2d_jps(st2, en2, 0.5, map_ids=mid2)
+    dt = time.perf_counter() - t0
+    print(f"JPS run {rep}: {len(first)} searches in {dt * 1e3:.1f} ms = {len(first) / dt:.0f} searches/s; paths {int((jln > 0).sum())}, expanded nodes mean {jst[:, 0].mean():.0f} max {jst[:, 0].max()}", flush=True)
+k2 = min(len(first), 256)
+t0 = time.perf_counter()
+for i in range(k2):
+    wl.plan2d_jps(tb.world(int(tb.scen[first[i]])), st2[i], en2[i], 0.5)
+dt = time.perf_counter() - t0
+print(f"JPS CPU restatement, one thread: {k2} searches in {dt:.2f} s = {k2 / dt:.0f} searches/s")
