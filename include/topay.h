@@ -295,8 +295,9 @@ topay_status topay_connect_collision(topay_ctx* ctx, int map_id, int n_edges, co
  * cap_points are reported, not written), out_xy + p * cap_points * 2 = its points, first = start, last = goal: the raw
  * path topay_dense_path takes.  stats (n x 2, optional): expanded nodes, jump points before the cut.  The open list
  * follows boost::heap::d_ary_heap<arity<2>> with the reference's compare_state (graph_search.h:20-38; boost is not part of
- * the reference's sources, its sift rules are restated), which is what decides between equal-cost paths.  One thread per
- * search; the search state (21 bytes per map cell and search) is allocated for the call. */
+ * the reference's sources, its sift rules are restated), which is what decides between equal-cost paths.  One wavefront per
+ * search (lane 0 runs the heap, the wave scans the jumps); the search state (21 bytes per map cell and search) is allocated
+ * for the call. */
 topay_status topay_plan2d_jps(topay_ctx* ctx, int n, const int* map_ids /* n, NULL = slot 0 */, const double* start_xy /* n x 2 */,
                               const double* end_xy /* n x 2 */, double threshold, int cap_points, int* out_len, double* out_xy, int* stats);
 

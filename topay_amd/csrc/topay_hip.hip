@@ -2018,7 +2018,7 @@ topay_status topay_plan2d_jps(topay_ctx* c, int n, const int* map_ids, const dou
     B.inst0 = i0;
     B.n = std::min(chunk, n - i0);
     HIPCHK(hipMemsetAsync(B.flag, 0, (size_t)B.n * ncell, c->stream));
-    hipLaunchKernelGGL(topay::k_jps, dim3((unsigned)((B.n + 63) / 64)), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, B);
+    hipLaunchKernelGGL(topay::k_jps, dim3((unsigned)B.n), dim3(64), 0, c->stream, (const DevMap*)c->dmaps.p, B);   // one wave per search
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(out_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

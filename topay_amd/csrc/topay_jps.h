@@ -5,11 +5,13 @@
 // boost::heap::d_ary_heap<arity<2>, mutable_<true>> with compare_state (graph_search.h:20-38); boost is a third-party
 // dependency that is not part of /root/reference, its sift rules are restated (they decide which of several equal-cost
 // paths comes out).
-// A best-first search is one sequential chain of heap operations, so the unit of parallelism is the search: one THREAD
-// per (start, goal) pair -- a benchmark sweep plans 1024 scenarios at once, a planner its handful per cycle.  The search
-// state lives in HBM, per instance: g, parent, heap position per cell, one byte of flags + direction, and the heap.
-// The recursion of jump() is unrolled: a diagonal jump is a loop that tries the two straight jumps of every cell it
-// passes, a straight jump a plain loop.
+// A best-first search is one sequential chain of heap operations, so the unit of parallelism is the search: one WAVE per
+// (start, goal) pair -- a benchmark sweep plans 1024 scenarios at once, a planner its handful per cycle.  Lane 0 owns the
+// search state (HBM, per instance: g, parent, heap position per cell, one byte of flags + direction, and the heap) and
+// runs the serial part -- pop, successor bookkeeping, heap sifts; the jumps, which only read the map, are the wave's: a
+// straight jump tests 64 successive cells at a time (free / goal / forced neighbour) and a ballot finds the first cell
+// at which the sequential loop would have stopped.  The recursion of jump() is unrolled: a diagonal jump is a loop that
+// tries the two straight jumps of every cell it passes.
 #pragma once
 #include "topay_front.h"
 
@@ -109,19 +111,26 @@ __device__ __forceinline__ bool jps_has_forced(const JpsCtx& C, int x, int y, in
   }
   return false;
 }
-// jump along a straight direction (norm1 = 1): no inner jumps
-__device__ inline bool jps_jump_straight(const JpsCtx& C, int x, int y, int dx, int dy, int& ox, int& oy) {
-  for (;;) {
-    x += dx; y += dy;
-    if (!jps_free(C, x, y)) return false;
-    ox = x; oy = y;
-    if (x == C.xg && y == C.yg) return true;
-    if (jps_has_forced(C, x, y, dx, dy)) return true;
+// jump along a straight direction (norm1 = 1): no inner jumps.  Wave-collective (uniform arguments): lane l tests cell
+// base + l; the first cell that is blocked, the goal, or has a forced neighbour is where the sequential loop stops.
+__device__ inline bool jps_jump_straight(const JpsCtx& C, int lane, int x, int y, int dx, int dy, int& ox, int& oy) {
+  for (int base = 1;; base += 64) {
+    const int i = base + lane, cx = x + i * dx, cy = y + i * dy;
+    const bool fr = jps_free(C, cx, cy);
+    const bool stop = !fr || (cx == C.xg && cy == C.yg) || jps_has_forced(C, cx, cy, dx, dy);
+    const unsigned long long m = __ballot(stop);
+    if (m) {
+      const int f = __ffsll((long long)m) - 1;
+      if (!__shfl((int)fr, f)) return false;
+      ox = x + (base + f) * dx;
+      oy = y + (base + f) * dy;
+      return true;
+    }
   }
 }
 // jump(): straight or diagonal; a diagonal step first tries the two straight jumps from the new cell (ns[id][.][0..1])
-__device__ inline bool jps_jump(const JpsCtx& C, int x, int y, int dx, int dy, int& ox, int& oy) {
-  if (dx == 0 || dy == 0) return jps_jump_straight(C, x, y, dx, dy, ox, oy);
+__device__ inline bool jps_jump(const JpsCtx& C, int lane, int x, int y, int dx, int dy, int& ox, int& oy) {
+  if (dx == 0 || dy == 0) return jps_jump_straight(C, lane, x, y, dx, dy, ox, oy);
   for (;;) {
     x += dx; y += dy;
     if (!jps_free(C, x, y)) return false;
@@ -129,8 +138,8 @@ __device__ inline bool jps_jump(const JpsCtx& C, int x, int y, int dx, int dy, i
     if (x == C.xg && y == C.yg) return true;
     if (jps_has_forced(C, x, y, dx, dy)) return true;
     int tx, ty;
-    if (jps_jump_straight(C, x, y, dx, 0, tx, ty)) return true;
-    if (jps_jump_straight(C, x, y, 0, dy, tx, ty)) return true;
+    if (jps_jump_straight(C, lane, x, y, dx, 0, tx, ty)) return true;
+    if (jps_jump_straight(C, lane, x, y, 0, dy, tx, ty)) return true;
   }
 }
 __device__ __forceinline__ void jps_pos_to_index(const DevMap& M, double px, double py, int& ix, int& iy) {
@@ -155,8 +164,8 @@ __device__ inline bool jps_line_collides(const JpsCtx& C, double ax, double ay, 
   return false;
 }
 
-__global__ void k_jps(const DevMap* maps, const JpsBatch B) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_jps(const DevMap* maps, const JpsBatch B) {
+  const int p = blockIdx.x, lane = threadIdx.x;
   if (p >= B.n) return;
   JpsCtx C;
   const int gp = B.inst0 + p;   // global instance: inputs and results (the workspace is per launch)
@@ -169,31 +178,40 @@ __global__ void k_jps(const DevMap* maps, const JpsBatch B) {
   const double sx = B.start[2 * (size_t)gp], sy = B.start[2 * (size_t)gp + 1], ex = B.end[2 * (size_t)gp], ey = B.end[2 * (size_t)gp + 1];
   int* stats = B.stats + 2 * (size_t)gp;
   double* out = B.out_xy + (size_t)gp * B.cap * 2;
-  stats[0] = 0; stats[1] = 0;
-  B.out_len[gp] = 0;
+  if (lane == 0) { stats[0] = 0; stats[1] = 0; B.out_len[gp] = 0; }
   int xs, ys, xg, yg;
   jps_pos_to_index(C.M, sx, sy, xs, ys);
   jps_pos_to_index(C.M, ex, ey, xg, yg);
   if (xs < 0 || ys < 0 || xs >= C.nx || ys >= C.ny || xg < 0 || yg < 0 || xg >= C.nx || yg >= C.ny) return;
   C.xg = xg; C.yg = yg;
   const int goal_id = xg * C.ny + yg, start_id = xs * C.ny + ys;
-  // flag byte: 1 seen, 2 opened, 4 closed, (dx + 1) << 3, (dy + 1) << 5
-  C.g[start_id] = 0.0;
-  C.parent[start_id] = -1;
-  C.flag[start_id] = 1 | 2 | (1 << 3) | (1 << 5);
-  jps_push(C, start_id);
+  // flag byte: 1 seen, 2 opened, 4 closed, (dx + 1) << 3, (dy + 1) << 5.  Everything below that touches g / parent / flag /
+  // the heap is lane 0's.
+  if (lane == 0) {
+    C.g[start_id] = 0.0;
+    C.parent[start_id] = -1;
+    C.flag[start_id] = 1 | 2 | (1 << 3) | (1 << 5);
+    jps_push(C, start_id);
+  }
   int expanded = 0, cur = -1;
-  bool found = false;
+  int state = 0;   // 0 searching, 1 goal popped, 2 given up
   for (;;) {
-    expanded++;
-    cur = jps_pop(C);
-    C.flag[cur] |= 4;
-    if (cur == goal_id) { found = true; break; }
+    int cdx = 0, cdy = 0;
+    if (lane == 0) {
+      expanded++;
+      cur = jps_pop(C);
+      C.flag[cur] |= 4;
+      if (cur == goal_id) state = 1;
+      cdx = ((C.flag[cur] >> 3) & 3) - 1;
+      cdy = ((C.flag[cur] >> 5) & 3) - 1;
+    }
+    state = __shfl(state, 0);
+    if (state) break;
+    cur = __shfl(cur, 0); cdx = __shfl(cdx, 0); cdy = __shfl(cdy, 0);
     const int cx = cur / C.ny, cy = cur % C.ny;
-    const int cdx = ((C.flag[cur] >> 3) & 3) - 1, cdy = ((C.flag[cur] >> 5) & 3) - 1;
     const int norm1 = abs(cdx) + abs(cdy);
     const int num_neib = norm1 == 0 ? 8 : (norm1 == 1 ? 1 : 3), num_fneib = norm1 == 0 ? 0 : 2;
-    bool astar_error = false;
+    bool astar_error = false;   // (lane 0's)
     for (int dev = 0; dev < num_neib + num_fneib; ++dev) {
       int nxn, nyn, dx, dy;
       if (dev < num_neib) {
@@ -206,13 +224,14 @@ __global__ void k_jps(const DevMap* maps, const JpsBatch B) {
           dx = dev == 1 ? 0 : cdx;
           dy = dev == 0 ? 0 : cdy;
         }
-        if (!jps_jump(C, cx, cy, dx, dy, nxn, nyn)) continue;
+        if (!jps_jump(C, lane, cx, cy, dx, dy, nxn, nyn)) continue;
       } else {
         int fx, fy;
         jps_f1(cdx, cdy, dev - num_neib, fx, fy, dx, dy);
         if (jps_free(C, cx + fx, cy + fy)) continue;
-        if (!jps_jump(C, cx, cy, dx, dy, nxn, nyn)) continue;
+        if (!jps_jump(C, lane, cx, cy, dx, dy, nxn, nyn)) continue;
       }
+      if (lane != 0 || astar_error) continue;   // (after "ASTAR ERROR!" the reference has left the loop: nothing more is processed)
       const int nid = nxn * C.ny + nyn;
       if (!(C.flag[nid] & 1)) {
         C.flag[nid] = (unsigned char)(1 | ((dx + 1) << 3) | ((dy + 1) << 5));
@@ -233,17 +252,18 @@ __global__ void k_jps(const DevMap* maps, const JpsBatch B) {
           C.flag[nid] = (unsigned char)((fl & 7) | ((ndx + 1) << 3) | ((ndy + 1) << 5));
         } else if ((fl & 2) && (fl & 4)) {
           astar_error = true;   // "ASTAR ERROR!": the reference gives up
-          break;
         } else {
           C.flag[nid] = fl | 2;
           jps_push(C, nid);
         }
       }
     }
-    if (astar_error) break;
-    if (expanded >= 10000000) break;
-    if (C.hn == 0) break;
+    if (lane == 0 && (astar_error || expanded >= 10000000 || C.hn == 0)) state = 2;
+    state = __shfl(state, 0);
+    if (state) break;
   }
+  if (lane != 0) return;   // the rest is serial: path recovery and the zigzag cut
+  const bool found = state == 1;
   stats[0] = expanded;
   if (!found) return;
   // recoverPath: ids from the goal back to the start, kept in the heap array (free now)
