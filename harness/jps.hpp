@@ -100,43 +100,37 @@ struct JPS2DNeib {   // graph_search.cpp:583-669
         id++;
       }
   }
+  // The neighbours that are always expanded (graph_search.cpp:609-636): all eight at the start node in the order
+  // (1,0) (-1,0) (0,1) (1,1) (-1,1) (0,-1) (1,-1) (-1,-1); the move itself for a straight move; for a diagonal move its
+  // horizontal part, its vertical part, then the move.
   static void Neib(int dx, int dy, int norm1, int dev, int& tx, int& ty) {
-    switch (norm1) {
-      case 0:
-        switch (dev) {
-          case 0: tx = 1; ty = 0; return;
-          case 1: tx = -1; ty = 0; return;
-          case 2: tx = 0; ty = 1; return;
-          case 3: tx = 1; ty = 1; return;
-          case 4: tx = -1; ty = 1; return;
-          case 5: tx = 0; ty = -1; return;
-          case 6: tx = 1; ty = -1; return;
-          case 7: tx = -1; ty = -1; return;
-        }
-      case 1: tx = dx; ty = dy; return;
-      case 2:
-        switch (dev) {
-          case 0: tx = dx; ty = 0; return;
-          case 1: tx = 0; ty = dy; return;
-          case 2: tx = dx; ty = dy; return;
-        }
+    if (norm1 == 0) {
+      static const int ex[8] = {1, -1, 0, 1, -1, 0, 1, -1}, ey[8] = {0, 0, 1, 1, 1, -1, -1, -1};
+      tx = ex[dev];
+      ty = ey[dev];
+    } else if (norm1 == 1) {
+      tx = dx;
+      ty = dy;
+    } else {
+      tx = dev == 1 ? 0 : dx;
+      ty = dev == 0 ? 0 : dy;
     }
   }
+  // The cells whose being blocked forces a neighbour, and that neighbour (graph_search.cpp:638-669).  Straight move: the
+  // two cells beside the arrival cell (across the direction of travel), neighbour = that side, one step on.  Diagonal
+  // move: the cells behind the arrival cell along either axis, neighbour = the move mirrored in that axis.
   static void FNeib(int dx, int dy, int norm1, int dev, int& fx, int& fy, int& nx, int& ny) {
-    switch (norm1) {
-      case 1:
-        switch (dev) {
-          case 0: fx = 0; fy = 1; break;
-          case 1: fx = 0; fy = -1; break;
-        }
-        if (dx == 0) fx = fy, fy = 0;   // switch order if different direction
-        nx = dx + fx; ny = dy + fy;
-        return;
-      case 2:
-        switch (dev) {
-          case 0: fx = -dx; fy = 0; nx = -dx; ny = dy; return;
-          case 1: fx = 0; fy = -dy; nx = dx; ny = -dy; return;
-        }
+    if (norm1 == 1) {
+      const int side = dev == 0 ? 1 : -1;
+      fx = dx == 0 ? side : 0;
+      fy = dx == 0 ? 0 : side;
+      nx = dx + fx;
+      ny = dy + fy;
+    } else if (norm1 == 2) {
+      fx = dev == 0 ? -dx : 0;
+      fy = dev == 0 ? 0 : -dy;
+      nx = dev == 0 ? -dx : dx;
+      ny = dev == 0 ? dy : -dy;
     }
   }
 };
