@@ -82,3 +82,18 @@ for k1 in range(5):
         q = big & (cb == k1) & (ca == k2)
         if q.any():
             print(f"    class {k1+1} -> class {k2+1}: {int(q.sum())} gaps, mean {gap[q].mean()/1e3:.0f} ms, total {gap[q].sum()/1e6:.1f} slot-s; same batch {int((bb[q]==ba[q]).sum())}")
+
+# Steady-state accounting with the waves of every workgroup counted (a candidate of more than 32 pieces holds two SIMDs, of
+# more than 64 four): busy slot-time inside the window from the first start of batch 2 to the last end of the third batch
+# from the end, against 1024 x the window.
+wv = np.where(Nm <= 32, 1, np.where(Nm <= 64, 2, 4)).astype(float)
+if len(rec) >= 6:
+    w0 = (rec[2][1] - base).min(); w1 = (rec[-3][1] - base + rec[-3][2]).max()
+    busy = 0.0; per_batch = []
+    for (i, s, u, th, hw_) in rec:
+        s = s - base; e = s + u
+        ov = np.clip(np.minimum(e, w1) - np.maximum(s, w0), 0, None)
+        busy += (ov * wv).sum()
+        per_batch.append(float((u * wv).sum() / 1e6))
+    print(f"  steady window {w0/1e3:.0f}..{w1/1e3:.0f} ms: busy {busy/1e6:.1f} slot-s of {1024*(w1-w0)/1e6:.1f} = {busy/(1024*(w1-w0)):.3f}; "
+          f"slot-seconds per batch (elapsed x waves): {[round(v, 1) for v in per_batch]}")
