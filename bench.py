@@ -67,6 +67,11 @@ def host_cores():
 
 
 def main():
+    # stdout carries the one JSON line and nothing else: whatever libraries print there meanwhile (RCCL's version banner
+    # when the first communicator is created) goes to stderr
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -479,8 +484,10 @@ def main():
                               "sample": f"BASELINE configs[0]: first {n1} trajectories one after the other on one thread, "
                                         f"{r1['seconds']:.1f} s, mean {1e3 * r1['seconds'] / n1:.0f} ms per candidate"},
         }
+    sys.stdout.flush()
+    os.dup2(_real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
