@@ -39,8 +39,33 @@ __constant__ DevParams g_P;
 #define TOPAY_SCHED_FENCE() do { } while (0)
 #endif
 
+// The compiler must treat the value as changed (no instruction is emitted): stops common-subexpression reuse across a
+// rarely taken path, which would otherwise be paid for with registers on the common one.
+#ifndef TOPAY_CPU_EMU
+#define TOPAY_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define TOPAY_OPAQUE(x) do { } while (0)
+#endif
+
+// A wave-uniform `true` the compiler cannot see through (one s_cmp + s_cbranch): starts a new basic block on purpose.
+__device__ __forceinline__ bool topay_opaque_true() {
+#ifndef TOPAY_CPU_EMU
+  int one = 1;
+  asm volatile("" : "+s"(one));
+  return one != 0;
+#else
+  return true;
+#endif
+}
+
 #ifndef TOPAY_ESDF_LOOKAHEAD
 #define TOPAY_ESDF_LOOKAHEAD 2
+#endif
+#ifndef TOPAY_OCC2_FENCE
+#define TOPAY_OCC2_FENCE 1
+#endif
+#ifndef TOPAY_ESDF_LOOKAHEAD_OCC2
+#define TOPAY_ESDF_LOOKAHEAD_OCC2 1
 #endif
 
 namespace topay {
@@ -357,6 +382,7 @@ struct EvalCtx {
   lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
   glb_dp sbuf;   // HBM [14][sb_stride]: per-sample gradient rows parked between the cost and the gradient phase
   int sb_stride;
+  glb_dp mstash; // HBM [sb_stride][36]: forces of self-colliding sphere pairs of a sample (manipulator_block; rarely touched)
   lds_dp pw;     // [26][6]    integer powers jj^k of the Simpson sample index (constant for the whole solve)
   lds_dp X;      // union region: band + reciprocal diagonal (14*rows) | sample buffers (26N + 960)
   // global
@@ -519,6 +545,7 @@ __device__ __forceinline__ void band_sweep(lds_dp v, lds_cdp band, lds_cdp rdiag
 
 // MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
 // factors (+ reciprocal diagonal) stashed in C.lu.
+template <int OCC>
 __device__ __noinline__ void minco_generate(EvalCtx& C) {
   // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
   // is a flat (generic address space) load that the compiler must repeat after every LDS store.
@@ -710,6 +737,11 @@ __device__ __forceinline__ void joint_rotate(double* R, int i, double c_, double
 struct ManiIn {
   double pos[10];
   double omg, step, sth, cth;
+  // this sample's 36 doubles of the candidate's self-collision block in HBM (only touched by a lane whose arm really
+  // collides with itself; [sample][36], so that every entry is the base plus a constant offset -- a strided layout costs a
+  // 64-bit address per entry); act = 0: a padding lane (its results are dropped, it never writes)
+  glb_dp stash;
+  int act;
 };
 struct ManiOut {
   double g[10];
@@ -726,6 +758,15 @@ __device__ long long g_mani_stamps[8];
 #else
 #define MSTAMP(k) do { } while (0)
 #endif
+// Register plan (round 4).  OCC = waves per SIMD the caller's kernel is built for: 1 -> 512 registers per lane, 2 -> 256.
+// The block used to hold the 12 sphere centres AND 12 force accumulators (144 VGPRs) because the rare self-collision
+// pairs add to the forces of two spheres at once, ahead of the per-sphere terms.  Now a sphere's force is born in the
+// iteration of the sphere loop that consumes its centre (the arm-local force takes the centre's registers), and the pair
+// contributions -- needed by fewer than one sample in a thousand -- are accumulated in an HBM block by the lanes that
+// have any, in the pair order of before, and read back at the top of the sphere's iteration: same operands, same order,
+// same bits as the 144-register version.  LA = spheres whose ESDF gathers are issued ahead (2 with one wave per SIMD;
+// 1 with two, where the other wave covers the latency and the request registers are what is scarce).
+template <int OCC>
 __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, const ManiIn in) {
   const DevParams& P = g_P;
   const DevMap M = load_map(mp);
@@ -757,7 +798,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
   }
   const double p0x = pos[0] + (cth * P.relT[0] - sth * P.relT[1]);
   const double p0y = pos[1] + (sth * P.relT[0] + cth * P.relT[1]);
-  const double p0z = P.chassis_height + P.relT[2];
+  const double p0z = P.p0z;
   // walk 1: world sphere centres (the arm-local rho_k are not kept; the torque walks below regenerate them)
   // spheres per link: link0:{0,1} 1:{2} 2:{3,4} 3:{5} 4:{6,7} 5:{8} 6:{9,10} 7:{11}
   double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
@@ -785,41 +826,59 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     }
   }
   MSTAMP(1);  // walk 1
-  double Gx[TOPAY_NSPH], Gy[TOPAY_NSPH], Gz[TOPAY_NSPH];
-#pragma unroll
-  for (int k = 0; k < TOPAY_NSPH; k++) { Gx[k] = 0.0; Gy[k] = 0.0; Gz[k] = 0.0; }
   cost = 0.0;
   gdTk = 0.0;
   const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
   // sphere pairs: collision_matrix == -1 <=> non-adjacent spheres (moma_param.h:128-143: at the zero pose
   // only self and neighbouring spheres overlap) — moma_traj_opt.cpp:1566-1611
-  // One branch per sphere a instead of one per pair: the clearances of (a, b > a+1) are independent straight-line
-  // arithmetic (instruction-level parallelism is all a single wave per SIMD has), and only a lane that sees a
-  // positive one walks the penalty path, which recomputes the same expressions.
+  // The clearances of all 55 pairs are independent straight-line arithmetic; only a lane that sees a positive one walks
+  // the penalty path, which recomputes the same expressions and keeps the forces of the two spheres in its column of the
+  // HBM block (read-modify-write, pair order).
+  bool anypair;
+  {
+    double worst[TOPAY_NSPH - 2];
+    double wall = -1.0;
 #pragma unroll
-  for (int a = 0; a < TOPAY_NSPH - 2; a++) {
-    double worst = -1.0;
-#pragma unroll
-    for (int b = a + 2; b < TOPAY_NSPH; b++) {
-      const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
-      const double rr = P.sph_r[a] + P.sph_r[b];
-      const double dist = rr * rr - fma(dz, dz, fma(dy, dy, dx * dx));
-      worst = fmax(worst, dist);
-    }
-    if (worst > 0) {
+    for (int a = 0; a < TOPAY_NSPH - 2; a++) {
+      worst[a] = -1.0;
 #pragma unroll
       for (int b = a + 2; b < TOPAY_NSPH; b++) {
         const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
-        const double rr = P.sph_r[a] + P.sph_r[b];
-        const double dist = rr * rr - fma(dz, dz, fma(dy, dy, dx * dx));
-        if (dist > 0) {
-          double pe, pd;
-          smoothL1(dist, mu, pe, pd);
-          const double sc = -w * wSC * pd * 2.0;
-          Gx[a] = fma(sc, dx, Gx[a]); Gy[a] = fma(sc, dy, Gy[a]); Gz[a] = fma(sc, dz, Gz[a]);
-          Gx[b] = fma(-sc, dx, Gx[b]); Gy[b] = fma(-sc, dy, Gy[b]); Gz[b] = fma(-sc, dz, Gz[b]);
-          gdTk += omg * wSC * (pe * TOPAY_INV_K);
-          cost += w * wSC * pe;
+        const double dist = P.pair_rr2[a * TOPAY_NSPH + b] - fma(dz, dz, fma(dy, dy, dx * dx));
+        worst[a] = fmax(worst[a], dist);
+      }
+      wall = fmax(wall, worst[a]);
+    }
+    anypair = in.act != 0 && wall > 0;
+    if (anypair) {
+      // (the centres are made opaque here: otherwise the compiler keeps the 165 coordinate differences of the screening
+      // above alive for this path -- in scratch memory -- instead of recomputing the few it needs)
+#pragma unroll
+      for (int k = 0; k < TOPAY_NSPH; k++) { TOPAY_OPAQUE(Px[k]); TOPAY_OPAQUE(Py[k]); TOPAY_OPAQUE(Pz[k]); }
+      const glb_dp sg = in.stash;
+#pragma unroll
+      for (int v = 0; v < 3 * TOPAY_NSPH; v++) sg[v] = 0.0;
+#pragma unroll
+      for (int a = 0; a < TOPAY_NSPH - 2; a++) {
+        if (worst[a] > 0) {
+#pragma unroll
+          for (int b = a + 2; b < TOPAY_NSPH; b++) {
+            const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
+            const double dist = P.pair_rr2[a * TOPAY_NSPH + b] - fma(dz, dz, fma(dy, dy, dx * dx));
+            if (dist > 0) {
+              double pe, pd;
+              smoothL1(dist, mu, pe, pd);
+              const double sc = -w * wSC * pd * 2.0;
+              sg[3 * a + 0] = fma(sc, dx, sg[3 * a + 0]);
+              sg[3 * a + 1] = fma(sc, dy, sg[3 * a + 1]);
+              sg[3 * a + 2] = fma(sc, dz, sg[3 * a + 2]);
+              sg[3 * b + 0] = fma(-sc, dx, sg[3 * b + 0]);
+              sg[3 * b + 1] = fma(-sc, dy, sg[3 * b + 1]);
+              sg[3 * b + 2] = fma(-sc, dz, sg[3 * b + 2]);
+              gdTk += omg * wSC * (pe * TOPAY_INV_K);
+              cost += w * wSC * pe;
+            }
+          }
         }
       }
     }
@@ -827,42 +886,48 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
   MSTAMP(2);  // sphere pairs
   // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520)
   double bFx = 0.0, bFy = 0.0, bMz = 0.0;  // base: x, y, yaw (everything rotates about the vertical axis through (x, y))
-  constexpr int LA = TOPAY_ESDF_LOOKAHEAD;  // spheres whose gathers are issued ahead
+  constexpr int LA = OCC >= 2 ? TOPAY_ESDF_LOOKAHEAD_OCC2 : TOPAY_ESDF_LOOKAHEAD;  // spheres whose gathers are issued ahead
   Esdf3dReq rq[LA + 1];
+  double Lx[TOPAY_NSPH], Ly[TOPAY_NSPH], Lz[TOPAY_NSPH];   // arm-local forces g' = A^T g
 #pragma unroll
   for (int k = 0; k < LA; k++) esdf3d_issue(M, Px[k], Py[k], Pz[k], rq[k]);
 #pragma unroll
   for (int k = 0; k < TOPAY_NSPH; k++) {
     if (k + LA < TOPAY_NSPH) esdf3d_issue(M, Px[k + LA], Py[k + LA], Pz[k + LA], rq[(k + LA) % (LA + 1)]);
+    double Gx = 0.0, Gy = 0.0, Gz = 0.0;
+    if (anypair) {
+      const glb_cdp sg = in.stash;
+      Gx = sg[3 * k + 0]; Gy = sg[3 * k + 1]; Gz = sg[3 * k + 2];
+    }
     if (k >= 3) {
-      const double height = P.chassis_height + P.relT[2] + P.sph_r[k] - Pz[k];
+      const double height = P.sph_top[k] - Pz[k];
       if (height > 0) {
         double pe, pd;
         smoothL1(height, mu, pe, pd);
-        Gz[k] += -w * wSC * pd;
+        Gz += -w * wSC * pd;
         gdTk += omg * wSC * (pe * TOPAY_INV_K);
         cost += w * wSC * pe;
       }
     }
     double d, gx, gy, gz;
     esdf3d_finish(M, rq[k % (LA + 1)], d, gx, gy, gz);
-    const double viola = P.sph_r[k] * 10.0 * 1.1 - d * 10.0;
+    const double viola = P.sph_viol[k] - d * 10.0;
     if (viola > 0) {
       double pe, pd;
       smoothL1(viola, mu, pe, pd);
       const double sc = -w * wMC * pd;
-      Gx[k] += sc * gx * 10.0; Gy[k] += sc * gy * 10.0; Gz[k] += sc * gz * 10.0;
+      Gx += sc * gx * 10.0; Gy += sc * gy * 10.0; Gz += sc * gz * 10.0;
       gdTk += omg * wMC * (pe * TOPAY_INV_K);
       cost += w * wMC * pe;
     }
-    bFx += Gx[k];
-    bFy += Gy[k];
-    bMz = fma(Px[k] - pos[0], Gy[k], fma(-(Py[k] - pos[1]), Gx[k], bMz));
-    // g' = A^T g (arm-local frame), in place; world position no longer needed
-    const double tx = fma(A[6], Gz[k], fma(A[3], Gy[k], A[0] * Gx[k]));
-    const double ty = fma(A[7], Gz[k], fma(A[4], Gy[k], A[1] * Gx[k]));
-    const double tz = fma(A[8], Gz[k], fma(A[5], Gy[k], A[2] * Gx[k]));
-    Gx[k] = tx; Gy[k] = ty; Gz[k] = tz;
+    bFx += Gx;
+    bFy += Gy;
+    bMz = fma(Px[k] - pos[0], Gy, fma(-(Py[k] - pos[1]), Gx, bMz));
+    // g' = A^T g (arm-local frame); the world position is no longer needed
+    Lx[k] = fma(A[6], Gz, fma(A[3], Gy, A[0] * Gx));
+    Ly[k] = fma(A[7], Gz, fma(A[4], Gy, A[1] * Gx));
+    Lz[k] = fma(A[8], Gz, fma(A[5], Gy, A[2] * Gx));
+    if (OCC >= 2 && TOPAY_OCC2_FENCE) __builtin_amdgcn_sched_barrier(0);
     TOPAY_SCHED_FENCE();
   }
   MSTAMP(3);  // ESDF loop
@@ -882,10 +947,10 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
 #pragma unroll
       for (int c = 0; c < cnt; c++) {
         const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
-        Fx += Gx[sidx]; Fy += Gy[sidx]; Fz += Gz[sidx];
-        Mx = fma(ly, Gz[sidx], fma(-lz, Gy[sidx], Mx));
-        My = fma(lz, Gx[sidx], fma(-lx, Gz[sidx], My));
-        Mz = fma(lx, Gy[sidx], fma(-ly, Gx[sidx], Mz));
+        Fx += Lx[sidx]; Fy += Ly[sidx]; Fz += Lz[sidx];
+        Mx = fma(ly, Lz[sidx], fma(-lz, Ly[sidx], Mx));
+        My = fma(lz, Lx[sidx], fma(-lx, Lz[sidx], My));
+        Mz = fma(lx, Ly[sidx], fma(-ly, Lx[sidx], Mz));
         sidx++;
       }
       q0 = fma(R[2], P.colli_length[i], q0);
@@ -906,10 +971,10 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
 #pragma unroll
       for (int c = 0; c < cnt; c++) {  // remove link i's spheres from the "beyond" sums
         const double lx = fma(R[2], P.sph_off[sidx], o0), ly = fma(R[5], P.sph_off[sidx], o1), lz = fma(R[8], P.sph_off[sidx], o2);
-        Fx -= Gx[sidx]; Fy -= Gy[sidx]; Fz -= Gz[sidx];
-        Mx = fma(-ly, Gz[sidx], fma(lz, Gy[sidx], Mx));
-        My = fma(-lz, Gx[sidx], fma(lx, Gz[sidx], My));
-        Mz = fma(-lx, Gy[sidx], fma(ly, Gx[sidx], Mz));
+        Fx -= Lx[sidx]; Fy -= Ly[sidx]; Fz -= Lz[sidx];
+        Mx = fma(-ly, Lz[sidx], fma(lz, Ly[sidx], Mx));
+        My = fma(-lz, Lx[sidx], fma(lx, Lz[sidx], My));
+        Mz = fma(-lx, Ly[sidx], fma(ly, Lx[sidx], Mz));
         sidx++;
       }
       o0 = fma(R[2], P.colli_length[i], o0);
@@ -966,7 +1031,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
   const double w = omg * step;
 #pragma unroll
   for (int sgn = -1; sgn <= 1; sgn += 2) {
-    const double v = sgn * max_v * th1 + max_w * sd1 - max_v * max_w;
+    const double v = sgn * max_v * th1 + max_w * sd1 - P.max_vw;
     if (v > 0) {
       double pe, pd;
       smoothL1(v, mu, pe, pd);
@@ -979,7 +1044,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
   }
 #pragma unroll
   for (int sgn = -1; sgn <= 1; sgn += 2) {
-    const double v = sgn * max_v * th1 - max_w * sd1 - max_v * max_w;
+    const double v = sgn * max_v * th1 - max_w * sd1 - P.max_vw;
     if (v > 0) {
       double pe, pd;
       smoothL1(v, mu, pe, pd);
@@ -990,8 +1055,8 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
       cost += w * wM * pe;
     }
   }
-  const double vAcc = sd2 * sd2 - max_a * max_a;
-  const double vAlp = th2 * th2 - max_dw * max_dw;
+  const double vAcc = sd2 * sd2 - P.max_a2;
+  const double vAlp = th2 * th2 - P.max_dw2;
   if (vAcc > 0) {
     double pe, pd;
     smoothL1(vAcc, mu, pe, pd);
@@ -1032,12 +1097,49 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 // pcol = this lane's column of a [15][64] pass buffer (stash around the manipulator block, which needs the registers).
 // Shared by the one-wave and the several-waves evaluation: same arithmetic, same bits.
 // ---------------------------------------------------------------------------------------------
-template <int STAGE>
-__device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, int i, int j, double step, double half, double posx,
-                                            double posy, lds_dp pcol, const TOPAY_GLB DevMap* mp, double wM, double wA, double wD,
-                                            double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
+template <int STAGE, int OCC>
+__device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, int i, int j, int e, bool act, double step, double half,
+                                            double posx, double posy, const TOPAY_GLB DevMap* mp, double wM, double wA,
+                                            double wD, double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
   const DevParams& P = g_P;
   (void)C;
+  // Stage 2 starts with the manipulator block: it only needs the pose (theta, joints) of the sample, and everything else
+  // of the body is computed AFTER the call from the coefficients in LDS -- nothing of the sample has to be parked while
+  // the block owns the registers (rounds 1-3 parked 14 doubles per lane in an LDS pass buffer, 7.7 KB per wave, the
+  // largest single block of the LDS plan).  Every sum is formed in the order of before.
+  ManiOut mo_;
+  if (STAGE == 2) {
+    ManiIn min_;
+    {
+      const double s1 = j * half;
+      const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
+      double pv[9];
+#pragma unroll
+      for (int d = 0; d < 9; d++) {
+        if (d == 1) continue;   // (the arc length is not part of the pose)
+        lds_cdp c = cL + d * rows + 6 * i;
+        pv[d] = fma(c[5], s5, fma(c[4], s4, fma(c[3], s3, fma(c[2], s2, fma(c[1], s1, c[0])))));
+      }
+      min_.pos[0] = posx; min_.pos[1] = posy; min_.pos[2] = pv[0];
+#pragma unroll
+      for (int q = 0; q < 7; q++) min_.pos[3 + q] = pv[2 + q];
+      det_sincos(pv[0], &min_.sth, &min_.cth);
+    }
+    min_.omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
+    min_.step = step;
+    min_.stash = C.mstash + 36 * (act ? e : 0); min_.act = act ? 1 : 0;
+#ifdef TOPAY_STAMPS
+    const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // The call sits in a block of its own, entered by a SCALAR branch the compiler cannot fold: the register allocator
+    // parks what is live across the call at the top of the call's block, and when that block is the join of a divergent
+    // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (DESIGN.md section 9;
+    // tools/isa_lint.py found it again in round 4 when the callee's smaller register need changed the caller's allocation).
+    if (topay_opaque_true()) mo_ = manipulator_block<OCC>(mp, min_);
+#ifdef TOPAY_STAMPS
+    if (C.stamps && C.lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
+#endif
+  }
   Basis B;
   make_basis(j * half, B);
   const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
@@ -1049,15 +1151,13 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
   kinodynamic_block(P, wM, wA, wD, omg, step, real_alpha, th1, th2, th3, sd1, sd2, sd3, cst, gdTs, gB[1], gB[2],
                     gB[3], gB[4]);
   if (STAGE == 2) {
-    double sth, cth;
-    det_sincos(th0, &sth, &cth);
     // chassis collision — moma_traj_opt.cpp:1304-1332
     double d2, g2x, g2y;
     {
       const DevMap M = load_map(mp);
       esdf2d_query(M, posx, posy, d2, g2x, g2y);
     }
-    const double viola = P.chassis_colli_radius * 1.05 - d2;
+    const double viola = P.chassis_r105 - d2;
     if (viola > 0) {
       double pe, pd;
       smoothL1(viola, P.relu_mu, pe, pd);
@@ -1067,20 +1167,16 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
       gdTs += omg * P.s2_collision_weight * (pe * TOPAY_INV_K);
       cst += omg * step * P.s2_collision_weight * pe;
     }
-    // manipulator
-    double pos[10], q1[7];
-    pos[0] = posx; pos[1] = posy; pos[2] = th0;
-    double qacc = 0.0;  // moma_grad.tail(7) . dq
+    // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the rare gradBeta rows are
+    // produced in the follow-up round of the gradient phase when any lane is active), and moma_grad.tail(7) . dq
+    const double* mg = mo_.g;
+    double qacc = 0.0;
 #pragma unroll
     for (int q = 0; q < 7; q++) {
       double a0, a1, a2, a3;
       poly4(cL, rows, i, 2 + q, B, a0, a1, a2, a3);
-      pos[3 + q] = a0;
-      q1[q] = a1;
-      // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the
-      // rare gradBeta rows are produced in the follow-up round when any lane is active)
-      const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
-      const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+      const double vDq = a1 * a1 - P.joint_vel_limit2[q];
+      const double vD2q = a2 * a2 - P.joint_acc_limit2[q];
       if (vDq > 0) {
         double pe, pd;
         smoothL1(vDq, P.relu_mu, pe, pd);
@@ -1095,42 +1191,16 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
         cst += omg * step * P.s2_mani_acc_weight * pe;
         jva = true;
       }
+      gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
+      qacc += mg[3 + q] * a1;
       TOPAY_SCHED_FENCE();
     }
-    // park the per-sample context in this lane's LDS column while the manipulator block runs: it needs nearly
-    // the whole register budget for the 12 sphere centres and their gradients
-    pcol[0 * 64] = th1;
-#pragma unroll
-    for (int q = 0; q < 7; q++) pcol[(1 + q) * 64] = q1[q];
-#pragma unroll
-    for (int v = 1; v < 5; v++) pcol[(7 + v) * 64] = gB[v];
-    pcol[12 * 64] = gdTs;
-    pcol[13 * 64] = cst;
-    ManiIn min_;
-#pragma unroll
-    for (int q = 0; q < 10; q++) min_.pos[q] = pos[q];
-    min_.omg = omg; min_.step = step; min_.sth = sth; min_.cth = cth;
-#ifdef TOPAY_STAMPS
-    const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    const ManiOut mo_ = manipulator_block(mp, min_);
-#ifdef TOPAY_STAMPS
-    if (C.stamps && C.lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
-#endif
-    const double* mg = mo_.g;
-    cst = pcol[13 * 64] + mo_.cost;
-    gdTs = pcol[12 * 64] + mo_.gdT;
-#pragma unroll
-    for (int v = 1; v < 5; v++) gB[v] = pcol[(7 + v) * 64];
+    cst = cst + mo_.cost;
+    gdTs = gdTs + mo_.gdT;
     gpx += mg[0];
     gpy += mg[1];
     gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
-    gdTs += mg[2] * pcol[0 * 64] * real_alpha;   // (1670)
-#pragma unroll
-    for (int q = 0; q < 7; q++) {
-      gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
-      qacc += mg[3 + q] * pcol[(1 + q) * 64];
-    }
+    gdTs += mg[2] * th1 * real_alpha;   // (1670)
     gdTs += qacc * real_alpha;          // (1672)
   }
 }
@@ -1139,7 +1209,7 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
 // The evaluation.  STAGE = 1: firstStageCostCallback; STAGE = 2: secondStageCostCallback.
 // RMAX = system rows per lane (1: N <= 10, 2: N <= 21, 3: N <= 32).  Returns f (wave-uniform); writes g[n].
 // ---------------------------------------------------------------------------------------------
-template <int STAGE, int RMAX>
+template <int STAGE, int RMAX, int OCC = 1>
 __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
   // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
   // is a flat (generic address space) load that the compiler must repeat after every LDS store.
@@ -1164,7 +1234,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
   const DevParams& P = g_P;
   const int lane = C.lane, N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_cdp cL = C.cL;
-  minco_generate(C);
+  minco_generate<OCC>(C);
 
   // ---- jerk energy & dJ/dT per piece — minco.hpp:923-942, 978-994 (lanes <-> pieces)
   double jerk_gdT = 0.0, jerk_e = 0.0;
@@ -1263,7 +1333,7 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
       // after the call: state the caller keeps in VGPR lanes / scratch across a divergent call).
       // Lanes beyond the last sample evaluate the first sample of the last piece and their results are dropped.
       double cst;
-      sample_body<STAGE>(C, cL, rows, i, j, step, half, posx, posy, pbuf + lane, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
+      sample_body<STAGE, OCC>(C, cL, rows, i, j, e, act, step, half, posx, posy, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
       if (act) {
         cost_pen += cst;
       } else {
@@ -1478,8 +1548,8 @@ __device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap
           for (int q = 0; q < 7; q++) {
             double a0, a1, a2;
             poly3(cL, rows, i, 2 + q, B, a0, a1, a2);
-            const double vDq = a1 * a1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
-            const double vD2q = a2 * a2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+            const double vDq = a1 * a1 - P.joint_vel_limit2[q];
+            const double vD2q = a2 * a2 - P.joint_acc_limit2[q];
             if (vDq > 0) {
               double pe, pd;
               smoothL1(vDq, P.relu_mu, pe, pd);

@@ -104,7 +104,7 @@ __device__ __forceinline__ void carve_mw(EvalCtx& C, lds_dp base, int Nmax, int 
 
 // MINCO generate for an NW-wave workgroup: fills divided over all threads, LU on wave 0 (the pivots are a serial chain),
 // substitutions on lanes 0..8 of wave 0.  Same statements as minco_generate().
-template <int NW>
+template <int NW, int OCC>
 __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   constexpr int NT = 64 * NW;
   const lds_dp c_Tp = C.Tp;
@@ -212,7 +212,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
 // ---------------------------------------------------------------------------------------------
 // The evaluation, NW waves.  RMAX = system rows per thread (rows <= 64 NW RMAX), N <= 64 NW.
 // ---------------------------------------------------------------------------------------------
-template <int STAGE, int RMAX, int NW>
+template <int STAGE, int RMAX, int NW, int OCC = 1>
 __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
   constexpr int NT = 64 * NW;
   const lds_dp c_Tp = C.Tp;
@@ -245,7 +245,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const lds_dp ptot = c_red + 8;               // [<= 32][2] pass totals of the XY prefix / chain suffix
   const lds_dp csr = c_red + 8 + 64;           // [2][NW][64] pass costs of one round (two rounds in flight)
   TOPAY_LDS unsigned long long* jmask = (TOPAY_LDS unsigned long long*)(c_red + 8 + 64 + 2 * NW * 64);   // [NW]
-  minco_generate_mw<NW>(C);
+  minco_generate_mw<NW, OCC>(C);
 
   // ---- jerk energy & dJ/dT per piece (thread <-> piece; N <= NT)
   double jerk_gdT = 0.0, jerk_e = 0.0;
@@ -364,7 +364,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       bool jva = false;
       if (!skip_body) {   // (wave-uniform: no call of the non-inlined manipulator block under a partial EXEC mask, see topay_eval.h)
         double cst;
-        sample_body<STAGE>(C, cL, rows, i, j, step, half, posx, posy, pbuf + lane, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
+        sample_body<STAGE, OCC>(C, cL, rows, i, j, e, act, step, half, posx, posy, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
         if (act) cst_out = cst;
       }
       if (act && !skip_body) {
@@ -566,8 +566,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
           for (int q = 0; q < 7; q++) {
             double p0, p1, p2;
             poly3(cL, rows, i, 2 + q, B, p0, p1, p2);
-            const double vDq = p1 * p1 - P.joint_vel_limit[q] * P.joint_vel_limit[q];
-            const double vD2q = p2 * p2 - P.joint_acc_limit[q] * P.joint_acc_limit[q];
+            const double vDq = p1 * p1 - P.joint_vel_limit2[q];
+            const double vD2q = p2 * p2 - P.joint_acc_limit2[q];
             if (vDq > 0) {
               double pe, pd;
               smoothL1(vDq, P.relu_mu, pe, pd);

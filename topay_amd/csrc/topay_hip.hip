@@ -25,417 +25,7 @@
 #include "topay_jps.h"
 #include "topay_yaml.h"
 
-// Minimum waves per SIMD the register allocator must leave room for (512 / this = VGPR+AGPR budget per lane).
-// One wave per SIMD: the f64 manipulator block alone needs ~300 registers (12 sphere centres and their gradients,
-// two VGPRs per value), so a 256-register budget only moves that state into scratch -- measured 1.5-3x slower per
-// evaluation (offload-LTO builds that enforce 256 / 168 registers in the callees), while the 512-register build has
-// no VGPR spills in the evaluation and is the fastest variant ("Occupancy").
-#ifndef TOPAY_WAVES_PER_EU
-#define TOPAY_WAVES_PER_EU 1
-#endif
-
-using namespace topay;
-
-#ifndef TOPAY_CPU_EMU
-extern __shared__ double topay_lds[];
-#define TOPAY_LDS_PTR ((lds_dp)topay_lds)
-#else
-#define TOPAY_LDS_PTR ((lds_dp)hip_emu::S().dyn_smem)
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------------
-__global__ void k_init(DevBatch Bt, const double* paths, const long long* path_off, const int* path_len,
-                       const double* bvel, const double* bacc, double* scratch, int scratch_stride, int maxN, int stride_n) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= Bt.B) return;
-  init_one(g_P, paths + path_off[b] * 10, path_len[b], bvel + (size_t)b * 20, bacc + (size_t)b * 20,
-           scratch + (size_t)b * scratch_stride, maxN, Bt.N + b, Bt.s1_past + b, Bt.head + (size_t)b * 27,
-           Bt.tail + (size_t)b * 27, Bt.start_xy + 2 * b, Bt.goal_xy + 2 * b, Bt.init_xy + (size_t)b * 2 * maxN,
-           Bt.x0 + (size_t)b * stride_n);
-}
-
-// Where candidate b's variable-length blocks start: every per-candidate array is packed by the candidate's own size
-// (pieces before it: poff, decision-vector elements before it: noff), not strided by the longest member of the batch.
-__device__ __forceinline__ long long uniform_i64(long long v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
-  return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
-// LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
-template <int NW, bool MWE>
-__host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds, int compact) {
-  return !MWE ? lds_doubles(Nmax_lds) : lds_doubles_mw(Nmax_lds, NW, compact);
-}
-
-template <int RMAX, int NW, bool MWE>
-__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int compact) {
-  constexpr int NT = 64 * NW;
-  C.tid = threadIdx.x;
-  C.lane = threadIdx.x & 63;
-  C.wave = threadIdx.x >> 6;
-  C.N = __builtin_amdgcn_readfirstlane(Bt.N[b]);  // wave-uniform: keep it (and what derives from it) in scalar registers
-  C.rows = 6 * C.N;
-  C.n = 10 * C.N - 8;
-  C.red = nullptr; C.adj = nullptr; C.compact = 0; C.cl_in_lds = 1;
-  if (!MWE) carve(C, TOPAY_LDS_PTR, Nmax_lds);
-  else carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
-  fill_power_table(C.pw, C.lane);
-  for (int t = C.tid; t < 27; t += NT) {
-    C.hp[t] = Bt.head[(size_t)b * 27 + t];
-    C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
-  }
-  const long long po = uniform_i64(Bt.poff[b]);
-  C.lu = (glb_dp)(Bt.lu + 84 * po);
-  C.sb_stride = TOPAY_EP * C.N;
-  C.sbuf = (glb_dp)(Bt.sbuf + 14 * TOPAY_EP * po);
-  C.coefg = (glb_dp)(Bt.coef + 54 * po);
-  C.init_xy = (glb_cdp)(Bt.init_xy + (size_t)b * 2 * TOPAY_MAX_N);
-  C.sx = Bt.start_xy[2 * b]; C.sy = Bt.start_xy[2 * b + 1];
-  C.ex = Bt.goal_xy[2 * b];  C.ey = Bt.goal_xy[2 * b + 1];
-  C.fxe0 = 0.0; C.fxe1 = 0.0;
-  C.stamps = nullptr;
-  C.t_last = 0;
-#ifdef TOPAY_STAMPS
-  // diagnostic build: the trace buffer (topay_set_trace with cap >= 32) doubles as the stamp accumulator
-  if (Bt.trace && Bt.trace_cap >= 32) C.stamps = (TOPAY_GLB long long*)(Bt.trace + (size_t)b * Bt.trace_cap) + 8;
-  C.t_last = (long long)__builtin_amdgcn_s_memtime();
-#endif
-}
-
-// getTraj() state of the last evaluation (moma_traj_opt.h:943-946) into the candidate's result blocks
-template <int NW>
-__device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& Bt, int b) {
-  constexpr int NT = 64 * NW;
-  const int N = C.N, rows = C.rows;
-  const long long po = uniform_i64(Bt.poff[b]);
-  // (compact layout after a gradient phase: the coefficients already sit in the result block, C.cL holds the adjoint)
-  if (C.cl_in_lds) {
-    double* coef = Bt.coef + 54 * po;
-    for (int t = C.tid; t < 9 * rows; t += NT) coef[t] = C.cL[t];
-  }
-  for (int t = C.tid; t < N; t += NT) Bt.T[po + t] = C.Tp[t];
-  double* kn = Bt.knots + 2 * (po + b);
-  if (C.tid == 0) { kn[0] = C.sx; kn[1] = C.sy; }
-  for (int t = C.tid; t < 2 * N; t += NT) kn[2 + t] = C.pcs[2 * N + 2 + t];
-}
-
-// test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
-template <int RMAX, int NW, bool MWE>
-__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int compact, int repeats) {
-  const int b = Bt.order[blockIdx.x];
-  const bool commit = (stage & 16) != 0;
-  stage &= 15;
-  EvalCtx C;
-  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
-  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  const long long no = uniform_i64(Bt.noff[b]);
-  C.x = (glb_cdp)(Bt.x + no);
-  C.g = (glb_dp)(Bt.work + 4 * no);
-  C.lam0 = Bt.alm[4 * b]; C.lam1 = Bt.alm[4 * b + 1]; C.rho0 = Bt.alm[4 * b + 2]; C.rho1 = Bt.alm[4 * b + 3];
-  __syncthreads();
-  double f = 0.0;
-  // (negative repeats: cost only -- the gate then answers "gradient not needed", as for a rejected line-search trial)
-  const bool cost_only = repeats < 0;
-  if (cost_only) repeats = -repeats;
-  for (int r = 0; r < repeats; r++) {
-    GradGate gate;
-    gate.always = !cost_only; gate.has_early = false; gate.finit = 0.0; gate.thr = -1.0e300; gate.early = 0.0;
-    gate.early_ok = false; gate.skip_thr = 0.0;
-    if constexpr (!MWE) {
-      if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
-      else f = eval_cost_grad<2, RMAX>(C, mp, gate);
-    } else {
-      __syncthreads();
-      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW>(C, mp, gate);
-      else f = eval_cost_grad_mw<2, RMAX, NW>(C, mp, gate);
-    }
-  }
-  if (C.tid == 0) {
-    Bt.fout[b] = f;
-    Bt.xyerr[2 * b] = C.fxe0;
-    Bt.xyerr[2 * b + 1] = C.fxe1;
-  }
-  if (commit) {   // topay_load_solution: the spline of this x becomes the candidate's result, as after a solve that ended here
-    __syncthreads();
-    store_result<NW>(C, Bt, b);
-    if (C.tid == 0) { Bt.cost[b] = f; Bt.success[b] = 1; }
-  }
-}
-
-// The gate inside the solve kernel is a call: inlined, its 9 000 instructions and their live ranges became part of the
-// solver's register allocation (161 instead of 33 spilled VGPRs in k_solve1).
-__device__ __noinline__ void feasibility_gate_in_solve(const FeasIO F, const TOPAY_GLB DevMap* mp) { feasibility_gate(F, mp); }
-
-template <int RMAX, int NW, bool MWE>
-__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
-  constexpr int NT = 64 * NW;
-  const unsigned long long t_begin = wall_clock64();
-  // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
-  // is resident, see topay_optimize_async
-  if (threadIdx.x == 0 && Bt.started && Bt.N[b] <= Bt.gate_maxN) {
-#ifndef TOPAY_CPU_EMU
-    __hip_atomic_fetch_add(Bt.started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    Bt.started[0] += 1;
-#endif
-  }
-  EvalCtx C;
-  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
-  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW, MWE>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
-  const long long no = uniform_i64(Bt.noff[b]);
-  const int n = C.n;
-  SolveIO S;
-  S.x = (glb_dp)(Bt.x + no);
-  S.g = (glb_dp)(Bt.work + 4 * no);
-  S.xp = (glb_dp)(Bt.work + 4 * no + n);
-  S.gp = (glb_dp)(Bt.work + 4 * no + 2 * (long long)n);
-  S.d = (glb_dp)(Bt.work + 4 * no + 3 * (long long)n);
-  S.hist_s = (glb_dp)(Bt.hist_s + (long long)Bt.hist_m * no);
-  S.hist_y = (glb_dp)(Bt.hist_y + (long long)Bt.hist_m * no);
-  S.hist_ys = (glb_dp)(Bt.hist_ys + (size_t)b * Bt.hist_m);
-  S.hist_al = (glb_dp)(Bt.hist_alpha + (size_t)b * Bt.hist_m);
-  S.nstride = n;
-  S.stats = (glb_ip)(Bt.stats + (size_t)b * 8);
-  S.trace = Bt.trace ? (glb_dp)(Bt.trace + (size_t)b * Bt.trace_cap) : (glb_dp)nullptr;
-  S.trace_cap = Bt.trace_cap;
-  const int grp = Bt.group_id ? __builtin_amdgcn_readfirstlane(Bt.group_id[b]) : -1;
-  S.grp_tau = (grp >= 0 && Bt.cancel_budget > 0) ? (TOPAY_GLB int*)(Bt.group_tau + grp) : (TOPAY_GLB int*)nullptr;
-  S.cancel_flag = (const TOPAY_GLB int*)Bt.cancel_flag;
-  S.cancel_budget = Bt.cancel_budget;
-  // x <- x0
-  {
-    const double* x0 = Bt.x0 + (size_t)b * (10 * TOPAY_MAX_N - 8);
-    for (int e = C.tid; e < C.n; e += NT) S.x[e] = x0[e];
-  }
-  int success = 0, interrupted = 0;
-  double cost = 0.0;
-  solve_trajectory<RMAX, NW, MWE>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
-  // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
-  __syncthreads();
-  store_result<NW>(C, Bt, b);
-  if (Bt.gate_in_solve) {
-    // printConstraintsSituations of the returned trajectory (planner.cpp:878-880) by wave 0, from the result blocks just
-    // written; panels and sample times go to the candidate's L-BFGS history blocks, which are dead now
-    __syncthreads();
-    int* fl = Bt.feas_flags + 2 * b;
-    if (interrupted) {
-      if (C.tid == 0) { fl[0] = 0; fl[1] = 0; }
-    } else if (threadIdx.x < 64) {
-      const long long po = uniform_i64(Bt.poff[b]);
-      const long long hist_doubles = (long long)Bt.hist_m * C.n;
-      FeasIO F;
-      F.coef = Bt.coef + 54 * po;
-      F.T = Bt.T + po;
-      F.N = C.N;
-      F.x0 = C.sx; F.y0 = C.sy;
-      F.th0 = Bt.head[(size_t)b * 27];
-      F.cseq = Bt.hist_s + (long long)Bt.hist_m * no;
-      F.tk = Bt.hist_y + (long long)Bt.hist_m * no;
-      F.cap_panels = hist_doubles / 2 - 1;
-      F.cap_samples = hist_doubles;
-      F.report = Bt.feas_report + (size_t)b * 38;
-      F.feasible = fl;
-      feasibility_gate_in_solve(F, mp);
-      // first feasible success of its planning call: its work clock opens the 100 ms (cancel_budget) window of the others
-      if (S.grp_tau && success) {
-        wave_global_sync();
-        if (C.tid == 0 && fl[0]) {
-          const int clock = (S.stats[2] + S.stats[5]) * C.N;
-          atomicMin((int*)S.grp_tau, clock);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (C.tid == 0) {
-    if (Bt.interrupted) Bt.interrupted[b] = interrupted;
-    Bt.success[b] = success;
-    Bt.cost[b] = cost;
-    Bt.xyerr[2 * b] = C.fxe0;
-    Bt.xyerr[2 * b + 1] = C.fxe1;
-    Bt.alm[4 * b] = C.lam0; Bt.alm[4 * b + 1] = C.lam1; Bt.alm[4 * b + 2] = C.rho0; Bt.alm[4 * b + 3] = C.rho1;
-    Bt.elapsed_us[b] = (double)(wall_clock64() - t_begin) * 0.01;
-    Bt.start_us[b] = (double)t_begin * 0.01;
-#ifndef TOPAY_CPU_EMU
-    {
-      const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-      const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
-      Bt.hw_id[b] = (int)(((xcc & 0xF) << 16) | (((hw >> 13) & 0x7) << 12) | (((hw >> 8) & 0xF) << 4) | ((hw >> 4) & 0x3));
-    }
-#else
-    Bt.hw_id[b] = 0;
-#endif
-  }
-}
-
-// The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
-// (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
-// of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX, int NW, bool MWE>
-__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int compact, int my_class) {
-  const bool queued = B.queue_next != nullptr;
-  const int lowest = queued ? B.queue_lowest : my_class;
-  for (int cls = my_class; cls >= lowest; cls--) {
-    const int count = queued ? B.queue_count[cls] : 1, off = queued ? B.queue_off[cls] : (int)blockIdx.x;
-    for (int once = 0;; once++) {
-      int pos = 0;
-      if (queued) {
-        if (threadIdx.x == 0) pos = atomicAdd(B.queue_next + cls, 1);
-        if (NW == 1) {
-          pos = __shfl(pos, 0);
-        } else {   // the position travels to the other waves through the first LDS word (nothing of a solve is live here)
-          TOPAY_LDS int* w0 = (TOPAY_LDS int*)TOPAY_LDS_PTR;
-          if (threadIdx.x == 0) w0[0] = pos;
-          __syncthreads();
-          pos = w0[0];
-          __syncthreads();
-        }
-      } else {
-        pos = once;
-      }
-      if (pos >= count) break;
-      solve_one<RMAX, NW, MWE>(B, maps, Nmax_lds, compact, B.order[off + pos]);
-      __syncthreads();
-    }
-  }
-}
-
-// Persistent launch: the grid is one workgroup per SIMD slot (or fewer; a workgroup of NW waves takes NW slots), and
-// every workgroup takes candidates from the launch's queue -- positions of `order`, longest first -- until it is empty.
-// The hardware dispatcher places workgroups in order on a fixed round-robin of XCDs / shader engines and stalls on a
-// full one while others have room (about 10 % of the slots stay empty when it has to place 8000 workgroups of unequal
-// length); a resident workgroup that fetches its next candidate itself leaves no slot idle and starts candidates
-// strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
-// not (nothing is shared between candidates).
-template <int RMAX, int NW, bool MWE>
-__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact) {
-  drain_queues<RMAX, NW, MWE>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
-}
-
-// One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32 / 42 / 64.  Several waves per trajectory
-// (topay_eval_mw.h): k_solve<rows per thread>w<waves>, rows <= 64 x waves x rows per thread.
-#define TOPAY_SOLVE_KERNEL(NAME, R, W, M)                                                                           \
-  __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds, int compact) { \
-    solve_body<R, W, M>(Bt, maps, Nmax_lds, compact);                                                               \
-  }
-#define TOPAY_EVAL_KERNEL(NAME, R, W, M)                                                                            \
-  __global__ void __launch_bounds__(64 * W, TOPAY_WAVES_PER_EU) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds, int compact) { \
-    eval_body<R, W, M>(Bt, maps, stage, Nmax_lds, compact, repeats);                                                \
-  }
-TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, false)
-TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, false)
-TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, false)
-TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, false)
-TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, false)
-TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, true)
-TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, true)
-TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, true)
-TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, true)
-TOPAY_EVAL_KERNEL(k_eval1, 1, 1, false)
-TOPAY_EVAL_KERNEL(k_eval2, 2, 1, false)
-TOPAY_EVAL_KERNEL(k_eval3, 3, 1, false)
-TOPAY_EVAL_KERNEL(k_eval4, 4, 1, false)
-TOPAY_EVAL_KERNEL(k_eval6, 6, 1, false)
-TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2, true)
-TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2, true)
-TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, true)
-TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4, true)
-
-// feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
-__global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
-                                                 long long cap_samples, double* report, int* flags) {
-  const int b = blockIdx.x;
-  const int N = Bt.N[b];
-  if (N <= 0) {
-    if (threadIdx.x == 0) { flags[2 * b] = 0; flags[2 * b + 1] = 0; }
-    return;
-  }
-  FeasIO F;
-  F.coef = Bt.coef + 54 * Bt.poff[b];
-  F.T = Bt.T + Bt.poff[b];
-  F.N = N;
-  F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
-  F.th0 = Bt.head[(size_t)b * 27];
-  F.cseq = cseq + (size_t)b * 2 * (cap_panels + 1);
-  F.tk = tk + (size_t)b * cap_samples;
-  F.cap_panels = cap_panels; F.cap_samples = cap_samples;
-  F.report = report + (size_t)b * 38;
-  F.feasible = flags + 2 * b;
-  const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  feasibility_gate(F, mp);
-}
-
-// MomaParam::getMeshPose of n states, one thread per state
-__global__ void __launch_bounds__(64) k_mesh_pose(topay_mesh_params_t K, int n, const double* states, double* parts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double st[10];
-  for (int k = 0; k < 10; k++) st[k] = states[(size_t)i * 10 + k];
-  mesh_pose(K, st, parts + (size_t)i * 77);
-}
-
-// MomaTraj playback of one candidate (car_seq + getState at given times)
-__global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cseq, long long cap_panels, int nq, const double* times,
-                                                 double* states, double* seq_out, int* nseq_out) {
-  const int N = Bt.N[b];
-  if (N <= 0) {
-    if (threadIdx.x == 0) *nseq_out = 0;
-    return;
-  }
-  FeasIO F;
-  F.coef = Bt.coef + 54 * Bt.poff[b];
-  F.T = Bt.T + Bt.poff[b];
-  F.N = N;
-  F.x0 = Bt.start_xy[2 * b]; F.y0 = Bt.start_xy[2 * b + 1];
-  F.th0 = Bt.head[(size_t)b * 27];
-  F.cseq = cseq;
-  F.tk = nullptr;
-  F.cap_panels = cap_panels; F.cap_samples = 0;
-  F.report = nullptr;
-  F.feasible = nullptr;
-  playback(F, nq, times, states, seq_out, nseq_out);
-}
-
-// getTraj() of a selection of candidates, packed by pieces (topay_get_results): one workgroup per selected candidate
-__global__ void k_gather_results(DevBatch Bt, int n, const int* idx, const int* piece_off, double* durations, double* coeffs,
-                                 double* knots) {
-  const int k = blockIdx.x;
-  if (k >= n) return;
-  const int b = idx[k];
-  const int N = piece_off[k + 1] - piece_off[k];
-  if (N <= 0) return;
-  const int rows = 6 * N, p0 = piece_off[k];
-  const double* cm = Bt.coef + 54 * Bt.poff[b];   // [9][rows], element d * rows + 6 p + k = coefficient of t^k
-  for (int t = threadIdx.x; t < N * 54; t += blockDim.x) {
-    const int p = t / 54, r = t - 54 * p, d = r / 6, kk = r - 6 * d;
-    coeffs[(size_t)p0 * 54 + t] = cm[(size_t)d * rows + 6 * p + 5 - kk];   // per piece 9 x 6, highest order first
-  }
-  for (int t = threadIdx.x; t < N; t += blockDim.x) durations[p0 + t] = Bt.T[Bt.poff[b] + t];
-  for (int t = threadIdx.x; t < 2 * (N + 1); t += blockDim.x) knots[2 * (size_t)(p0 + k) + t] = Bt.knots[2 * (Bt.poff[b] + b) + t];
-}
-
-// GridMap::isWholeBodyCollision for a batch of states
-__global__ void k_whole_body(const DevMap* maps, int map_id, int n, const double* states, int* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const DevMap M = maps[map_id];
-  out[i] = whole_body_collision(M, states + (size_t)i * 10) ? 1 : 0;
-}
-
-// test hook for the deterministic elementary functions: out[4i..4i+3] = sin(a_i), cos(a_i), atan2(a_i, b_i), -
-__global__ void k_math(const double* a, const double* b, double* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s, c;
-  det_sincos(a[i], &s, &c);
-  out[4 * i] = s;
-  out[4 * i + 1] = c;
-  out[4 * i + 2] = det_atan2(a[i], b[i]);
-  out[4 * i + 3] = sqrt(fabs(a[i])) / (1.0 + fabs(b[i]));
-}
+#include "topay_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -450,6 +40,15 @@ static void set_err(const std::string& s) { g_err = s; }
       return TOPAY_ERR_NO_DEVICE;                                                                \
     }                                                                                            \
   } while (0)
+
+// Tuning switches read from the environment exist only in builds with -DTOPAY_EXPERIMENTS (tools/ab_lib.sh); the product
+// library reads TOPAY_PERSISTENT / TOPAY_STEAL (launch scheme, used by the profiling scripts and the parity tests),
+// TOPAY_RCCL_LIB, and sets GPU_MAX_HW_QUEUES when it is loaded.
+#ifdef TOPAY_EXPERIMENTS
+static const char* exp_env(const char* name) { return getenv(name); }
+#else
+static const char* exp_env(const char*) { return nullptr; }
+#endif
 
 struct DevBuf {
   void* p = nullptr;
@@ -470,7 +69,7 @@ struct DevBuf {
     bytes = n;
     // debugging aid (TOPAY_POISON=<byte>): fill every fresh allocation, so that a read of memory nobody has written
     // shows up on every run instead of only when the allocator hands out dirty pages
-    static const int poison = [] { const char* e = getenv("TOPAY_POISON"); return e ? atoi(e) : -1; }();
+    static const int poison = [] { const char* e = exp_env("TOPAY_POISON"); return e ? atoi(e) : -1; }();
     if (poison >= 0) {
       HIPCHK(hipMemset(p, poison, n));
       HIPCHK(hipDeviceSynchronize());
@@ -513,22 +112,25 @@ struct ClassDef {
   solve_kernel_t solve;
   eval_kernel_t eval;
   int mwe = 0;   // the evaluation of topay_eval_mw.h (always for nw > 1); with one wave: in its compact LDS layout
+  int occ = 1;   // waves per SIMD the kernel is built for (512 / occ registers per lane)
 };
 static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
-        {10, 1, 1, k_solve1, k_eval1}, {15, 2, 1, k_solve2, k_eval2}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
-        {42, 2, 2, k_solve2w2, k_eval2w2}, {64, 3, 2, k_solve3w2, k_eval3w2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
-    // Two waves for N = 33..64 by default: measured on one box with three batches in flight (tools/r3_mw_ab.sh), one /
-    // two / four waves for both classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 /
+        {10, 1, 1, k_solve1, k_eval1, 0, 2}, {15, 2, 1, k_solve2, k_eval2, 0, 2}, {21, 2, 1, k_solve2, k_eval2, 0, 2}, {32, 3, 1, k_solve3, k_eval3, 0, 2},
+        {42, 2, 2, k_solve2w2, k_eval2w2, 0, 2}, {64, 3, 2, k_solve3w2, k_eval3w2, 0, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 0, 2}};
+    // Two waves per trajectory for N = 33..64: measured on one box with three batches in flight (tools/experiments/r3_mw_ab.sh),
+    // one / two / four waves for both classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 /
     // 1.03 s.  Four waves halve a long candidate's solve but occupy four SIMD slots for it (the serial parts -- LU,
     // substitutions -- leave three of them idle), two waves fill the SIMD the candidate's LDS would idle anyway.
+#ifdef TOPAY_EXPERIMENTS
     auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     const int w4 = env_nw("TOPAY_MW_C4", 2), w5 = env_nw("TOPAY_MW_C5", 2);
-    if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4};
-    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4};
-    if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6};
-    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4};
+    if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4, 0, 2};
+    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 0, 2};
+    if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6, 0, 2};
+    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 0, 2};
+#endif
     for (int k = 4; k < TOPAY_NBUCKET; k++) t[k].mwe = t[k].nw > 1;
     // (The templates also instantiate with one wave -- <R, 1, true>: the register-accumulator evaluation in its compact
     // 138 N-double LDS layout.  Measured for the common classes in round 3: bit-identical results, 1.7 % slower per step,
@@ -612,13 +214,14 @@ struct topay_ctx {
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
   int simd_slots = 1024;
+  double occ2_gain = 1.4;    // work per SIMD-second of the two-waves-per-SIMD classes relative to one wave per SIMD (sizes the launches only)
   DevBuf qnext;
   DevBuf mc_i, mc_d, mc_k, mc_rs, mc_in;   // node tables, Reeds-Shepp words and inputs of the last topay_mcrrt_plan
   int mc_n = 0, mc_node_cap = 0;
   DevBuf paths, path_off, path_len, bvel, bacc, scratch;
   DevBuf N, s1_past, map_id, head, tail, start_xy, goal_xy, init_xy, x0;
   DevBuf x, work, hist_s, hist_y, hist_ys, hist_alpha, lu;
-  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, hwid, sbuf, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
+  DevBuf success, cost, stats, xyerr, coef, T, knots, alm, fout, order, trace, elapsed, startus, hwid, sbuf, mstash, feas_cseq, feas_tk, feas_report, feas_flags, edt_occ, edt_tmp1, edt_tmp2, edt_v, edt_z, edt_out2, edt_out3, pb_io;
   float last_edt_ms = 0.f;
   int trace_cap = 0;
   DevBatch db;
@@ -682,6 +285,26 @@ static void make_dev_params(const topay_params_t& p, DevParams& d) {
   }
   for (int i = 0; i < 9; i++) d.relR[i] = p.relative_R[i];
   for (int i = 0; i < 3; i++) d.relT[i] = p.relative_t[i];
+  // derived constants (DevParams): the expressions of the evaluation, operation by operation (this file is compiled with
+  // -ffp-contract=off like the device code, so the host's products and sums are the device's)
+  for (int a = 0; a < TOPAY_NSPH; a++)
+    for (int b = 0; b < TOPAY_NSPH; b++) {
+      const double rr = d.sph_r[a] + d.sph_r[b];
+      d.pair_rr2[a * TOPAY_NSPH + b] = rr * rr;
+    }
+  for (int k = 0; k < TOPAY_NSPH; k++) {
+    d.sph_viol[k] = d.sph_r[k] * 10.0 * 1.1;
+    d.sph_top[k] = d.chassis_height + d.relT[2] + d.sph_r[k];
+  }
+  d.p0z = d.chassis_height + d.relT[2];
+  d.max_vw = d.max_v * d.max_w;
+  d.max_a2 = d.max_a * d.max_a;
+  d.max_dw2 = d.max_dw * d.max_dw;
+  d.chassis_r105 = d.chassis_colli_radius * 1.05;
+  for (int i = 0; i < 7; i++) {
+    d.joint_vel_limit2[i] = d.joint_vel_limit[i] * d.joint_vel_limit[i];
+    d.joint_acc_limit2[i] = d.joint_acc_limit[i] * d.joint_acc_limit[i];
+  }
 }
 
 static int sphere_layout_ok(const topay_params_t& p) {
@@ -820,20 +443,20 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     c->persistent = !(pe && pe[0] == '0');
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
-    c->simd_slots = 4 * prop.multiProcessorCount;   // one wave per SIMD (TOPAY_WAVES_PER_EU = 1), four SIMDs per CU
-    if (const char* sp = getenv("TOPAY_SLOTS_PER_SIMD")) c->simd_slots *= std::max(1, atoi(sp));   // (experiments with builds of TOPAY_WAVES_PER_EU > 1)
+    c->simd_slots = 4 * prop.multiProcessorCount;   // four SIMDs per CU; a class built for two waves per SIMD launches two workgroups per slot
+    if (const char* og = exp_env("TOPAY_OCC2_GAIN")) c->occ2_gain = std::max(0.5, atof(og));
     // A few slots are left to everything that is not a solve: the init kernel, the feasibility gate and the result
     // gather of the OTHER batches in flight, the runtime's copy kernels, a collective.  Resident solver waves own their
     // SIMD's whole register file, so on a device they fill completely such a kernel waits until workgroups exit.
     // TOPAY_RESERVE_SLOTS=<n> keeps n slots free (default 0: use every slot).
     {
-      const char* rs = getenv("TOPAY_RESERVE_SLOTS");
+      const char* rs = exp_env("TOPAY_RESERVE_SLOTS");
       const int reserve = rs ? atoi(rs) : 0;   // (measured: no gain from a standing reserve with two batches in flight)
       if (reserve > 0 && reserve < c->simd_slots / 2) c->simd_slots -= reserve;
     }
   }
   {
-    const char* g = getenv("TOPAY_DISPATCH_GATE");
+    const char* g = exp_env("TOPAY_DISPATCH_GATE");
     c->gate = !(g && g[0] == '0');
     void* hp = nullptr;
     HIPCHK(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -841,7 +464,7 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     c->h_started[0] = 0;
     c->h_cancel = c->h_started + 8;   // same pinned block: topay_cancel's flag
     c->h_cancel[0] = 0;
-    { const char* ge = getenv("TOPAY_GATE_IN_SOLVE"); c->gate_in_solve = !(ge && ge[0] == '0'); }
+    { const char* ge = exp_env("TOPAY_GATE_IN_SOLVE"); c->gate_in_solve = !(ge && ge[0] == '0'); }
   }
   if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
@@ -946,7 +569,7 @@ extern "C" topay_status topay_share_maps(topay_ctx* c, topay_ctx* owner, int fir
 
 static int bucket_of(int N) {
   // diagnostic: TOPAY_FORCE_CLASS=k sends every candidate that fits through launch class k (1-based) or a later one
-  static const int force = [] { const char* f = getenv("TOPAY_FORCE_CLASS"); return f ? atoi(f) : 0; }();
+  static const int force = [] { const char* f = exp_env("TOPAY_FORCE_CLASS"); return f ? atoi(f) : 0; }();
   int k0 = 0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
     if (N <= kBucketMaxN[k]) { k0 = k; break; }
@@ -1077,7 +700,7 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   };
   // Lines of up to 512 cells (every benchmark map: 200 x 200 x 16) take the exhaustive-search passes (topay_edt.h:
   // k_edt_direct / k_edt_tile, 32-bit squared distances between the passes); longer lines the serial envelope passes.
-  const bool small_lines = std::max(nx, std::max(ny, nz)) <= 512 && getenv("TOPAY_EDT_ENVELOPE") == nullptr;
+  const bool small_lines = std::max(nx, std::max(ny, nz)) <= 512 && exp_env("TOPAY_EDT_ENVELOPE") == nullptr;
   auto pick_w = [](long long lines) { int w = 1; for (int d = 1; d <= 64; d++) if (lines % d == 0) w = d; return w; };
   int* i1 = (int*)t1;
   int* i2 = (int*)t2;
@@ -1346,6 +969,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   ENS(alm, (size_t)batch * 4 * 8);
   ENS(fout, (size_t)batch * 8);
   ENS(sbuf, 14 * TOPAY_EP * P * 8);
+  ENS(mstash, 36 * TOPAY_EP * P * 8);
   ENS(elapsed, (size_t)batch * 8);
   ENS(startus, (size_t)batch * 8);
   ENS(hwid, (size_t)batch * 4);
@@ -1357,7 +981,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
     DevBuf* all[] = {&c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past, &c->map_id, &c->head, &c->tail,
                      &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->order, &c->poff, &c->noff, &c->x, &c->work, &c->hist_s, &c->hist_y,
                      &c->hist_ys, &c->hist_alpha, &c->lu, &c->success, &c->cost, &c->stats, &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm,
-                     &c->fout, &c->sbuf, &c->elapsed, &c->startus, &c->hwid};
+                     &c->fout, &c->sbuf, &c->mstash, &c->elapsed, &c->startus, &c->hwid};
     c->workspace_bytes = 0;
     for (DevBuf* q : all) c->workspace_bytes += q->bytes;
   }
@@ -1371,6 +995,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   d.xyerr = c->xyerr.as<double>(); d.coef = c->coef.as<double>(); d.T = c->T.as<double>();
   d.knots = c->knots.as<double>(); d.alm = c->alm.as<double>(); d.fout = c->fout.as<double>();
   d.sbuf = c->sbuf.as<double>();
+  d.mstash = c->mstash.as<double>();
   d.elapsed_us = c->elapsed.as<double>();
   d.start_us = c->startus.as<double>();
   d.hw_id = c->hwid.as<int>();
@@ -1402,34 +1027,37 @@ topay_status topay_reset(topay_ctx* c) {
 
 }  // extern "C"
 
-// Persistent grids: the slots are divided between the classes in proportion to an estimate of their work
-// (sum of N^1.5: the cost of an evaluation grows with N, the number of evaluations slowly; a several-waves workgroup
-// occupies NW slots for 1 / speed-up of the time), so that the launches of one batch together ask for exactly the
-// slots the device has and none of their workgroups waits in the dispatcher.  share[k] is in SLOTS.
-static void compute_shares(topay_ctx* c, int slots, int* share) {
+// Persistent grids.  A workgroup of class k occupies the fraction r_k of a compute unit -- the larger of its share of
+// the register file (NW waves of 512 / occ registers on four SIMDs of 512) and of the 160 KB of LDS -- for the time its
+// share of the class's work takes: work_k = sum of N^1.5 over the class (the cost of an evaluation grows with N, the
+// number of evaluations slowly), divided by the speed-up of NW waves, times the slow-down of a wave that shares its SIMD.
+// The grids are proportional to that workgroup-time and scaled so that together they ask for exactly the compute units
+// there are (x oversubscription): all launches of a batch end together and none of their workgroups waits in the
+// dispatcher.  nm[k] = longest candidate the class's LDS is sized for.
+static void compute_grids(topay_ctx* c, const int* nm, double cus, int* grid) {
   const ClassDef* ct = class_table();
-  double wk[topay_ctx::NBUCKET] = {0}, wt = 0.0;
+  double wt[topay_ctx::NBUCKET] = {0}, rk[topay_ctx::NBUCKET] = {0}, need = 0.0;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    double slot_cost = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.35 : 2.0);
+    grid[k] = 0;
+    if (c->cls[k].empty()) continue;
+    double t = ct[k].nw == 1 ? 1.0 : (ct[k].nw == 2 ? 1.0 / 1.48 : 0.5);   // time of a workgroup per unit of work
+    const double regs = (double)ct[k].nw / (4.0 * ct[k].occ), lds = (double)class_lds_bytes(ct[k], nm[k]) / (160.0 * 1024.0);
+    rk[k] = std::max(regs, lds);
+    // a wave that shares its SIMD runs slower (two of them get through occ2_gain times the work of one); classes whose LDS
+    // keeps them from sharing are not slowed down
+    if (ct[k].occ == 2 && lds <= 0.1875) t *= 2.0 / c->occ2_gain;
     // the smallest class's workgroups cannot take over anybody's queue, the others can take over its: it gets less than its share
-    // (measured, tools/r3_bias.sh, factor 1.0 / 0.9 / 0.8 / 0.7: serial step 1.00 / 0.99 / 0.98 / 0.97 s, pipelined 10.0-10.1k / 10.1k / 10.1k / 10.1k;
-    // further per-class factors from the launches' measured durations, tools/r3_mult.sh: nothing, 9.9-10.1k)
-    static const double bias0 = [] { const char* e = getenv("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 0.8; }();
-    if (k == 0) slot_cost *= bias0;
-    for (int b : c->cls[k]) wk[k] += slot_cost * std::pow((double)c->hN[b], 1.5);
-    wt += wk[k];
+    // (measured in round 3, tools/experiments/r3_bias.sh, factor 1.0 / 0.9 / 0.8 / 0.7: serial step 1.00 / 0.99 / 0.98 / 0.97 s)
+    static const double bias0 = [] { const char* e = exp_env("TOPAY_SHARE_BIAS0"); return e ? atof(e) : 0.8; }();
+    if (k == 0) t *= bias0;
+    for (int b : c->cls[k]) wt[k] += t * std::pow((double)c->hN[b], 1.5);
+    need += wt[k] * rk[k];
   }
-  int used = 0;
+  if (need <= 0.0) return;
+  const double G = cus / need;
   for (int k = 0; k < topay_ctx::NBUCKET; k++) {
-    const int nk = (int)c->cls[k].size(), nw = ct[k].nw;
-    int sh = nk == 0 ? 0 : std::min(nk * nw, std::max(nw, (int)std::floor(wk[k] / wt * slots)));
-    sh -= sh % nw;
-    share[k] = sh;
-    used += sh;
-  }
-  for (int k = 0; used < slots && k < 4 * topay_ctx::NBUCKET; k++) {   // hand the rounding remainder to classes that can use it
-    const int kk = k % topay_ctx::NBUCKET, nw = ct[kk].nw;
-    if (share[kk] > 0 && share[kk] + nw <= (int)c->cls[kk].size() * nw && used + nw <= slots) { share[kk] += nw; used += nw; }
+    if (c->cls[k].empty()) continue;
+    grid[k] = std::max(1, std::min((int)c->cls[k].size(), (int)std::floor(G * wt[k] + 0.5)));
   }
 }
 
@@ -1482,26 +1110,28 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
     HIPCHK(hipMemsetAsync(c->qnext.p, 0, sizeof(int) * topay_ctx::NBUCKET, c->stream));
     slots = c->simd_slots;
   }
-  int share[topay_ctx::NBUCKET] = {0};
+  int pgrid[topay_ctx::NBUCKET] = {0}, nmk[topay_ctx::NBUCKET] = {0};
+  for (int k = 0; k < topay_ctx::NBUCKET; k++) {
+    for (int b : c->cls[k]) nmk[k] = std::max(nmk[k], c->hN[b]);
+    // classes that may take over each other's queues run the same kernel: its LDS must hold the longest candidate of any of them
+    if (persistent && c->steal)
+      for (int k2 = steal_floor(k); k2 < k; k2++)
+        for (int b : c->cls[k2]) nmk[k] = std::max(nmk[k], c->hN[b]);
+  }
   if (persistent) {
     // 8 % more workgroups than SIMD slots: in steady state 3-5 % of the SIMDs have no workgroup because the ones still
     // pending do not find LDS on the compute units where a SIMD is free (54-107 KB workgroups beside 21-36 KB ones); a few
     // pending workgroups more, mostly of the small classes, fill those.  Measured, interleaved on one box
     // (TOPAY_OVERSUBSCRIBE=1.0 / 1.08): 10.01 / 10.20, 10.06 / 10.19, 10.04 / 10.07k trajectories/s; 1.2 is no better.
-    static const double over = [] { const char* e = getenv("TOPAY_OVERSUBSCRIBE"); return e ? atof(e) : 1.08; }();
-    compute_shares(c, (int)(slots * over), share);
+    static const double over = [] { const char* e = exp_env("TOPAY_OVERSUBSCRIBE"); return e ? atof(e) : 1.08; }();
+    compute_grids(c, nmk, slots / 4.0 * over, pgrid);
   }
   HIPCHK(hipEventRecord(c->bstart, c->stream));  // params + resets on the main stream come first
   for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
     const std::vector<int>& v = c->cls[k];
     const int nk = (int)v.size();
     if (nk == 0) continue;
-    int nm = 0;
-    for (int b : v) nm = std::max(nm, c->hN[b]);
-    // classes that may take over each other's queues run the same kernel: its LDS must hold the longest candidate of any of them
-    if (persistent && c->steal)
-      for (int k2 = steal_floor(k); k2 < k; k2++)
-        for (int b : c->cls[k2]) nm = std::max(nm, c->hN[b]);
+    const int nm = nmk[k];
     DevBatch d = c->db;
     d.order = c->db.order + off;
     int grid = nk;
@@ -1516,7 +1146,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
         d.queue_count[kk] = (int)c->cls[kk].size();
         o2 += d.queue_count[kk];
       }
-      grid = std::max(1, share[k] / ct[k].nw);
+      grid = pgrid[k];
     }
     off += nk;
     const size_t lds = class_lds_bytes(ct[k], nm);
@@ -2308,10 +1938,10 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
 
 // Kernel for a forced number of waves per trajectory (test hook topay_eval_waves): the smallest template that holds N.
 static bool class_for_waves(int N, int nw, ClassDef& out) {
-  static const ClassDef w1[] = {{10, 1, 1, k_solve1, k_eval1}, {21, 2, 1, k_solve2, k_eval2}, {32, 3, 1, k_solve3, k_eval3},
-                                {42, 4, 1, k_solve4, k_eval4}, {64, 6, 1, k_solve6, k_eval6}};
-  static const ClassDef w2[] = {{42, 2, 2, k_solve2w2, k_eval2w2}, {64, 3, 2, k_solve3w2, k_eval3w2}};
-  static const ClassDef w4[] = {{85, 2, 4, k_solve2w4, k_eval2w4}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4}};
+  static const ClassDef w1[] = {{10, 1, 1, nullptr, k_eval1, 0, 2}, {21, 2, 1, nullptr, k_eval2, 0, 2}, {32, 3, 1, nullptr, k_eval3, 0, 2},
+                                {42, 4, 1, nullptr, k_eval4, 0, 2}, {64, 6, 1, nullptr, k_eval6, 0, 2}};
+  static const ClassDef w2[] = {{42, 2, 2, nullptr, k_eval2w2, 0, 2}, {64, 3, 2, nullptr, k_eval3w2, 0, 2}};
+  static const ClassDef w4[] = {{85, 2, 4, nullptr, k_eval2w4, 0, 2}, {TOPAY_MAX_N, 3, 4, nullptr, k_eval3w4, 0, 2}};
   const ClassDef* t = nw == 1 ? w1 : (nw == 2 ? w2 : (nw == 4 ? w4 : nullptr));
   const int cnt = nw == 1 ? 5 : 2;
   if (!t) return false;

@@ -91,7 +91,7 @@ __device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int 
   return s;
 }
 
-template <int RMAX, int NW = 1, bool MWE = (NW > 1)>
+template <int RMAX, int NW = 1, bool MWE = (NW > 1), int OCC = 1>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
                                                  lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out, int& interrupted_out) {
   const DevParams& P = g_P;
@@ -204,11 +204,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       qk[12] = (unsigned long long)S.grp_tau; qk[13] = (unsigned long long)S.cancel_flag;
     }
     if constexpr (!MWE) {
-      if (stage == 1) f = eval_cost_grad<1, RMAX>(C, mp, gate);
-      else f = eval_cost_grad<2, RMAX>(C, mp, gate);
+      if (stage == 1) f = eval_cost_grad<1, RMAX, OCC>(C, mp, gate);
+      else f = eval_cost_grad<2, RMAX, OCC>(C, mp, gate);
     } else {
-      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW>(C, mp, gate);
-      else f = eval_cost_grad_mw<2, RMAX, NW>(C, mp, gate);
+      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
+      else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
       if (NW > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
       rp = 0;
     }

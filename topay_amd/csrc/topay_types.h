@@ -79,6 +79,17 @@ struct DevParams {
   double joint_acc_limit[7];
   double relR[9];
   double relT[3];
+  // Products and sums of the constants above that the evaluation needs per sample, formed once on the host with the
+  // same IEEE operations in the same order (make_dev_params): a wave-uniform f64 product is a VALU instruction on this
+  // hardware (there is no scalar f64 unit), and the compiler hoists such products out of the sample loop into registers
+  // it then spills.  As constants they are scalar loads at the point of use.
+  double pair_rr2[TOPAY_NSPH * TOPAY_NSPH];   // (r_a + r_b)^2
+  double sph_viol[TOPAY_NSPH];                // r_k * 10.0 * 1.1
+  double sph_top[TOPAY_NSPH];                 // chassis_height + relT[2] + r_k
+  double p0z;                                 // chassis_height + relT[2]
+  double max_vw, max_a2, max_dw2;             // max_v * max_w, max_a^2, max_dw^2
+  double chassis_r105;                        // chassis_colli_radius * 1.05
+  double joint_vel_limit2[7], joint_acc_limit2[7];
 };
 
 // Per-batch device arrays.  Fixed-size blocks are indexed by the candidate; the variable-length ones (everything sized
@@ -118,6 +129,7 @@ struct DevBatch {
   double* alm;        // [B][4] lambda0,1 rho0,1 (eval hook input / solver output)
   double* fout;       // [B] eval hook output
   double* sbuf;       // [182 poff]  [14][13 N] per-sample gradient rows parked between the cost and the gradient phase
+  double* mstash;     // [468 poff]  [13 N][36] forces of self-colliding sphere pairs of a sample (rarely touched, topay_eval.h)
   double* start_us;   // [B] start of the solve on the device's constant clock (scheduling diagnostics)
   // persistent launches: one queue per N-class = positions [queue_off[k], queue_off[k] + queue_count[k]) of `order`, handed
   // out through the device counters queue_next[k]; a workgroup of class queue_class drains its own queue, then the
