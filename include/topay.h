@@ -177,8 +177,10 @@ topay_status topay_get_map(topay_ctx* ctx, int map_id, double* esdf2d, double* e
 /* Map slots first_map_id .. first_map_id + n_maps - 1 of `ctx` become references to the resident maps of `owner` (same
  * device), without a copy: the maps are read-only for every entry point but the three that fill a slot.  The reference
  * hands one GridMap::Ptr to all of its optimisers (planner.cpp:59-75: every MomaTrajOpt gets the planner's grid_map);
- * here the contexts of the batches in flight share one set of fields the same way.  `owner` must outlive the use of
- * the shared slots and must not rebuild them while `ctx` solves. */
+ * here the contexts of the batches in flight share one set of fields the same way.  The library tracks the sharing:
+ * when `owner` refills one of the slots (topay_set_map, topay_build_esdf*), or is destroyed, every context that shares
+ * the slot first finishes its pending solve and then loses it -- its next use of the slot returns TOPAY_ERR_NO_MAP until
+ * it is shared or filled again; nothing is left pointing at freed or half-written fields. */
 topay_status topay_share_maps(topay_ctx* ctx, topay_ctx* owner, int first_map_id, int n_maps);
 
 /* All five fields of GridMap::updateESDF (src/map/src/grid_map.cpp:125-521).  Besides esdf2d and esdf3d (above) the

@@ -251,3 +251,29 @@ def test_record_gather_through_the_cabi_on_one_gpu():
     assert len(empty) == 0
     opt.comm_destroy()
     world.close()
+
+
+def test_shared_map_slots_are_invalidated_when_the_owner_refills_or_goes_away(cuboids_small):
+    """topay_share_maps hands out device pointers: when the owner refills a shared slot or is destroyed, the sharer must
+    lose the slot (TOPAY_ERR_NO_MAP) instead of keeping a dangling descriptor."""
+    from conftest import EMU_LIB, set_map
+    cs = cuboids_small
+    owner = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(owner, cs["world"])
+    a = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    a.share_maps(owner, 0, 1)
+    a.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    x = a.get_x(0)
+    f0 = a.eval(1, 0, x)[0]
+    set_map(owner, cs["world"])                      # the owner refills slot 0: new buffers may replace the old ones
+    with pytest.raises(api.TopayError):
+        a.eval(1, 0, x)                              # the resident batch used the slot: it has to be set again
+    with pytest.raises(api.TopayError):
+        a.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])   # ... and the slot is gone
+    a.share_maps(owner, 0, 1)
+    a.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    assert a.eval(1, 0, x)[0] == f0
+    owner.close()                                    # the owner goes away: same rule
+    with pytest.raises(api.TopayError):
+        a.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    a.close()

@@ -187,3 +187,36 @@ def test_playback_on_gpu_is_bit_identical_to_emulator(cuboids_small):
         T = opt.total_durations()[0]
         out[name] = opt.playback(0, np.linspace(-0.2, T + 0.2, 211))
     assert (out["gpu"][0] == out["emu"][0]).all() and (out["gpu"][1] == out["emu"][1]).all()
+
+
+def test_gate_with_a_short_history_block_falls_back_to_the_separate_kernel(cuboids_small):
+    """The in-solve gate borrows the candidate's L-BFGS history block as scratch.  With mem_size = 8 the block cannot hold
+    the panels and sample times of the returned trajectory: the solving wave must NOT gate a truncated sweep (round 3 did,
+    silently: violations in the tail went unsampled) -- it leaves the candidate to the separate kernel, whose scratch is
+    sized from the trajectory, and the verdicts equal those of the same splines gated through that kernel alone."""
+    cs = cuboids_small
+    p = api.default_params()
+    p.s1_lbfgs.mem_size = 8
+    p.s2_lbfgs.mem_size = 8
+    p.s2_lbfgs.max_iterations = 30
+    p.alm_max_outer = 1
+    emu = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    nb = 3
+    ok = emu.optimizeTraj(cs["lens"][:nb], cs["paths"][:cs["offs"][nb]])
+    feas, strict, rep = emu.check_feasible(report=True)
+    # reference route: the same splines loaded into a second context (a loaded trajectory is always gated by the separate kernel)
+    other = api.MomaTrajOptBatch(params=p, lib_path=EMU_LIB)
+    set_map(other, cs["world"])
+    other.set_init_traj(cs["lens"][:nb], cs["paths"][:cs["offs"][nb]])
+    alm = emu.alm_state()
+    for b in range(nb):
+        other.load_solution(b, emu.get_x(b), alm[b][:2], alm[b][2:])
+    f2, s2, r2 = other.check_feasible(report=True)
+    for b in range(nb):
+        if not ok[b]:
+            continue
+        assert feas[b] == f2[b] and strict[b] == s2[b]
+        assert np.array_equal(rep[b], r2[b])
+        assert np.isfinite(rep[b]).all()      # sampled, not skipped
+    emu.close(); other.close()

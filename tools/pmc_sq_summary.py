@@ -23,7 +23,7 @@ for k, d in agg.items():
 agg["all solve kernels"] = tot
 for k, d in sorted(agg.items()):
     w = d.get("SQ_WAVE_CYCLES", 0) or 1
-    print(f"{k}: " + ", ".join(f"{a}={b:.3g}" for a, b in sorted(d.items())))
+    print(f"{k}: " + ", ".join(f"{a}={b:.4g}" for a, b in sorted(d.items())))
     print(f"   issue any {d.get('SQ_ACTIVE_INST_ANY',0)/w:.3f}  VALU {d.get('SQ_ACTIVE_INST_VALU',0)/w:.3f}  LDS {d.get('SQ_ACTIVE_INST_LDS',0)/w:.3f}  "
           f"scalar {d.get('SQ_ACTIVE_INST_SCA',0)/w:.3f}  VMEM {d.get('SQ_ACTIVE_INST_VMEM',0)/w:.3f}  wait any {d.get('SQ_WAIT_ANY',0)/w:.3f}  "
           f"wait inst {d.get('SQ_WAIT_INST_ANY',0)/w:.3f}  busy/wave cycles {d.get('SQ_BUSY_CYCLES',0)/w:.3f}  "

@@ -334,10 +334,16 @@ __device__ __forceinline__ void esdf3d_issue(const DevMap& M, double px, double 
   clamp_pair(iy, ny - 1, y0, y1);
   clamp_pair(iz, nz - 1, z0, z1);
   glb_cdp e = M.esdf3d;
-  size_t b00 = ((size_t)x0 * ny + y0) * nz, b01 = ((size_t)x0 * ny + y1) * nz;
-  size_t b10 = ((size_t)x1 * ny + y0) * nz, b11 = ((size_t)x1 * ny + y1) * nz;
-  q.v000 = e[b00 + z0]; q.v001 = e[b00 + z1]; q.v010 = e[b01 + z0]; q.v011 = e[b01 + z1];
-  q.v100 = e[b10 + z0]; q.v101 = e[b10 + z1]; q.v110 = e[b11 + z0]; q.v111 = e[b11 + z1];
+  // One linear index with a multiply (integer multiplies run at a quarter of the vector rate), the other seven corners by
+  // adding the strides of the axes along which the clamped neighbour differs (x1 - x0, y1 - y0, z1 - z0 are 0 or 1).  A
+  // field has fewer than 2^32 cells (checked when the map is set), so the indices are 32-bit.
+  const unsigned i000 = ((unsigned)x0 * (unsigned)ny + (unsigned)y0) * (unsigned)nz + (unsigned)z0;
+  const unsigned sx = x1 != x0 ? (unsigned)(ny * nz) : 0u, sy = y1 != y0 ? (unsigned)nz : 0u, sz = z1 != z0 ? 1u : 0u;
+  const unsigned i001 = i000 + sz, i010 = i000 + sy, i100 = i000 + sx;
+  const unsigned i011 = i010 + sz, i101 = i100 + sz, i110 = i100 + sy;
+  const unsigned i111 = i110 + sz;
+  q.v000 = e[(size_t)i000]; q.v001 = e[(size_t)i001]; q.v010 = e[(size_t)i010]; q.v011 = e[(size_t)i011];
+  q.v100 = e[(size_t)i100]; q.v101 = e[(size_t)i101]; q.v110 = e[(size_t)i110]; q.v111 = e[(size_t)i111];
 }
 __device__ __forceinline__ void esdf3d_finish(const DevMap& M, const Esdf3dReq& q, double& dist, double& gx, double& gy,
                                               double& gz) {
@@ -376,7 +382,8 @@ struct EvalCtx {
   // LDS
   lds_dp cL;     // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
   lds_dp Tp;     // [5][N]     T, T^2..T^5
-  lds_dp hp;     // [54]       head PVA (27) | tail PVA (27), 9x3 col-major
+  glb_cdp hd, tl; // HBM [27] each: head / tail PVA, 9x3 col-major (read once per evaluation by the right-hand side)
+  int npass_lds;  // passes the pass-total block of the LDS plan is sized for
   lds_dp gdT;    // [N]        penalty dJ/dT accumulator
   lds_dp pcs;    // [4*(N+1)]  per-piece scratch: stage-1 tracking gradient (2N) | piece-end XY (2(N+1))
   lds_dp gC;     // [9][rows]  penalty dJ/dC accumulator, element (row, d) owned by the row lane of `row`
@@ -398,23 +405,6 @@ struct EvalCtx {
   long long t_last;
 };
 
-__host__ __device__ __forceinline__ int lds_doubles(int Nmax) {
-  const int rows = 6 * Nmax;
-  int xr = 14 * rows;
-  int sr = 26 * Nmax + 960;
-  return 18 * rows + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + 156 + (xr > sr ? xr : sr);
-}
-__device__ __forceinline__ void carve(EvalCtx& C, lds_dp base, int Nmax) {
-  const int rows = 6 * Nmax;
-  C.cL = base;
-  C.Tp = C.cL + 9 * rows;
-  C.hp = C.Tp + 5 * Nmax;
-  C.gdT = C.hp + 54;
-  C.pcs = C.gdT + Nmax;
-  C.gC = C.pcs + 4 * (Nmax + 1);
-  C.pw = C.gC + 9 * rows;
-  C.X = C.pw + 156;
-}
 // jj^k for jj = 0..25 (sample index within a piece; 25 is read but always multiplied by zero), k = 0..5: the local time of sample jj is jj * hs, so the
 // monomial basis of coefficient row k factors as (jj^k) * hs^k and the row lanes only need the three hs-powers
 // of their row (basis_k(k, hs)) once per pass instead of a power chain per sample.
@@ -541,124 +531,6 @@ __device__ __forceinline__ void band_sweep(lds_dp v, lds_cdp band, lds_cdp rdiag
       v[j] = xo[u];
     }
   }
-}
-
-// MINCO generate — minco.hpp:824-906 with banded_system.hpp:66-118.  Leaves c in C.cL and the LU
-// factors (+ reciprocal diagonal) stashed in C.lu.
-template <int OCC>
-__device__ __noinline__ void minco_generate(EvalCtx& C) {
-  // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
-  // is a flat (generic address space) load that the compiler must repeat after every LDS store.
-  const lds_dp c_Tp = C.Tp;
-  const lds_dp c_X = C.X;
-  const lds_dp c_gdT = C.gdT;
-  const lds_dp c_hp = C.hp;
-  const glb_dp c_lu = C.lu;
-  const glb_cdp c_x = C.x;
-
-  const DevParams& P = g_P;
-  const int lane = C.lane, N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
-  lds_dp band = c_X;
-  lds_dp rdiag = c_X + 13 * rows;
-  lds_dp cL = C.cL;
-  glb_cdp Tau = c_x;
-  glb_cdp Theta = c_x + N;
-  glb_cdp Arc = c_x + 2 * N - 1;
-  glb_cdp Vq = c_x + 3 * N - 1;
-
-  for (int t = lane; t < 13 * rows; t += 64) band[t] = 0.0;
-  for (int t = lane; t < 9 * rows; t += 64) cL[t] = 0.0;   // (gC is zeroed when the gradient phase starts)
-  if (lane < N) {
-    double T1 = expC2(Tau[lane]);  // calTfromTau, moma_traj_opt.h:778-786
-    double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
-    c_Tp[0 * N + lane] = T1; c_Tp[1 * N + lane] = T2; c_Tp[2 * N + lane] = T3;
-    c_Tp[3 * N + lane] = T4; c_Tp[4 * N + lane] = T5;
-    c_gdT[lane] = 0.0;
-  }
-  lds_sync();
-  // band fill — minco.hpp:838-896
-  if (lane == 0) {
-    BAND(0, 0) = 1.0; BAND(1, 1) = 1.0; BAND(2, 2) = 2.0;
-  }
-  if (lane < N - 1) {
-    const int i = lane;
-    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
-    const int r = 6 * i;
-    BAND(r + 3, r + 3) = 6.0;  BAND(r + 3, r + 4) = 24.0 * T1; BAND(r + 3, r + 5) = 60.0 * T2; BAND(r + 3, r + 9) = -6.0;
-    BAND(r + 4, r + 4) = 24.0; BAND(r + 4, r + 5) = 120.0 * T1; BAND(r + 4, r + 10) = -24.0;
-    BAND(r + 5, r) = 1.0; BAND(r + 5, r + 1) = T1; BAND(r + 5, r + 2) = T2; BAND(r + 5, r + 3) = T3;
-    BAND(r + 5, r + 4) = T4; BAND(r + 5, r + 5) = T5;
-    BAND(r + 6, r) = 1.0; BAND(r + 6, r + 1) = T1; BAND(r + 6, r + 2) = T2; BAND(r + 6, r + 3) = T3;
-    BAND(r + 6, r + 4) = T4; BAND(r + 6, r + 5) = T5; BAND(r + 6, r + 6) = -1.0;
-    BAND(r + 7, r + 1) = 1.0; BAND(r + 7, r + 2) = 2 * T1; BAND(r + 7, r + 3) = 3 * T2; BAND(r + 7, r + 4) = 4 * T3;
-    BAND(r + 7, r + 5) = 5 * T4; BAND(r + 7, r + 7) = -1.0;
-    BAND(r + 8, r + 2) = 2.0; BAND(r + 8, r + 3) = 6 * T1; BAND(r + 8, r + 4) = 12 * T2; BAND(r + 8, r + 5) = 20 * T3;
-    BAND(r + 8, r + 8) = -2.0;
-  }
-  if (lane == 63) {
-    const int i = N - 1, R0 = 6 * N;
-    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
-    BAND(R0 - 3, R0 - 6) = 1.0; BAND(R0 - 3, R0 - 5) = T1; BAND(R0 - 3, R0 - 4) = T2; BAND(R0 - 3, R0 - 3) = T3;
-    BAND(R0 - 3, R0 - 2) = T4; BAND(R0 - 3, R0 - 1) = T5;
-    BAND(R0 - 2, R0 - 5) = 1.0; BAND(R0 - 2, R0 - 4) = 2 * T1; BAND(R0 - 2, R0 - 3) = 3 * T2; BAND(R0 - 2, R0 - 2) = 4 * T3;
-    BAND(R0 - 2, R0 - 1) = 5 * T4;
-    BAND(R0 - 1, R0 - 4) = 2; BAND(R0 - 1, R0 - 3) = 6 * T1; BAND(R0 - 1, R0 - 2) = 12 * T2; BAND(R0 - 1, R0 - 1) = 20 * T3;
-  }
-  // right-hand side — minco.hpp:841-843, 879, 898-900; inner points from x (moma_traj_opt.cpp:904-913)
-  if (lane < 9) {
-    const int d = lane;
-    cL[d * rows + 0] = c_hp[0 * 9 + d];
-    cL[d * rows + 1] = c_hp[1 * 9 + d];
-    cL[d * rows + 2] = c_hp[2 * 9 + d];
-    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : c_hp[27 + 0 * 9 + d];  // minco_end_state(1,0) = Arc[N-1]
-    cL[d * rows + rows - 2] = c_hp[27 + 1 * 9 + d];
-    cL[d * rows + rows - 1] = c_hp[27 + 2 * 9 + d];
-  }
-  for (int t = lane; t < 9 * (N - 1); t += 64) {
-    const int i = t / 9, d = t - 9 * i;
-    // (joint index clamped instead of d - 2: the compiler may turn the branches into selects and issue the loads for
-    // every lane, and with a uniform base plus a 32-bit lane offset a negative index is an address 4 GB away)
-    const int dq = d >= 2 ? d - 2 : 0;
-    double v;
-    if (d == 0) v = Theta[i];
-    else if (d == 1) v = Arc[i];
-    else v = sigmoidC2(Vq[i * 7 + dq], P.joint_pos_limit_max[dq]);
-    cL[d * rows + 6 * i + 5] = v;
-  }
-  lds_sync();
-
-  STAMP(C, 0);  // fill
-  // LU without pivoting — banded_system.hpp:66-91.  Lane (t,u): row i = k+t (t=1..6), column j = k+u
-  // (u=0 stores the multiplier, u=1..6 the rank-1 update).  The zero-skip tests of the reference
-  // are arithmetic no-ops (0/x = 0, a - 0*c = a).
-  {
-    const int t = lane / 7 + 1, u = lane - (lane / 7) * 7;
-    for (int k = 0; k <= rows - 2; k++) {
-      const int i = k + t, j = k + u;
-      const bool act = (lane < 42) && (i < rows) && (j < rows);
-      double nv = 0.0;
-      if (act) {
-        const double akk = BAND(k, k), aik = BAND(i, k);
-        const double m = aik / akk;
-        nv = (u == 0) ? m : (BAND(i, j) - m * BAND(k, j));
-      }
-      lds_sync();
-      if (act) BAND(i, j) = nv;
-      lds_sync();
-    }
-  }
-  for (int t = lane; t < rows; t += 64) rdiag[t] = 1.0 / BAND(t, t);
-  lds_sync();
-  STAMP(C, 1);  // LU
-  // forward / backward substitution on the 9 right-hand sides — banded_system.hpp:96-118 (one lane per column)
-  if (lane < 9) {
-    band_sweep<0>(cL + lane * rows, band, rdiag, rows);
-    band_sweep<1>(cL + lane * rows, band, rdiag, rows);
-  }
-  // stash LU + reciprocal diagonal for the adjoint solve
-  for (int t = lane; t < 14 * rows; t += 64) c_lu[t] = c_X[t];
-  lds_sync();
-  STAMP(C, 2);  // substitutions + stash
 }
 
 // polynomial basis of local time s: b0 = s^k, b1, b2, b3 derivatives — moma_traj_opt.cpp:1263-1270
@@ -1203,610 +1075,6 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
     gdTs += mg[2] * th1 * real_alpha;   // (1670)
     gdTs += qacc * real_alpha;          // (1672)
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The evaluation.  STAGE = 1: firstStageCostCallback; STAGE = 2: secondStageCostCallback.
-// RMAX = system rows per lane (1: N <= 10, 2: N <= 21, 3: N <= 32).  Returns f (wave-uniform); writes g[n].
-// ---------------------------------------------------------------------------------------------
-template <int STAGE, int RMAX, int OCC = 1>
-__device__ __noinline__ double eval_cost_grad(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
-  // Local copies of the context fields: C lives in the caller's stack frame, and a field read through the reference
-  // is a flat (generic address space) load that the compiler must repeat after every LDS store.
-  const lds_dp c_Tp = C.Tp;
-  const lds_dp c_X = C.X;
-  const double c_ex = C.ex;
-  const double c_ey = C.ey;
-  const glb_dp c_g = C.g;
-  const lds_dp c_gdT = C.gdT;
-  const glb_cdp c_init_xy = C.init_xy;
-  const double c_lam0 = C.lam0;
-  const double c_lam1 = C.lam1;
-  const glb_dp c_lu = C.lu;
-  const lds_dp c_pcs = C.pcs;
-  const lds_dp c_pw = C.pw;
-  const double c_rho0 = C.rho0;
-  const double c_rho1 = C.rho1;
-  const double c_sx = C.sx;
-  const double c_sy = C.sy;
-  const glb_cdp c_x = C.x;
-
-  const DevParams& P = g_P;
-  const int lane = C.lane, N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
-  lds_cdp cL = C.cL;
-  minco_generate<OCC>(C);
-
-  // ---- jerk energy & dJ/dT per piece — minco.hpp:923-942, 978-994 (lanes <-> pieces)
-  double jerk_gdT = 0.0, jerk_e = 0.0;
-  if (lane < N) {
-    const int i = lane;
-    double w33 = 0, w43 = 0, w44 = 0, w53 = 0, w54 = 0, w55 = 0;
-#pragma unroll
-    for (int d = 0; d < 9; d++) {
-      const double c3 = cL[d * rows + 6 * i + 3], c4 = cL[d * rows + 6 * i + 4], c5 = cL[d * rows + 6 * i + 5];
-      const double e = P.energy_weights[d];
-      w33 += (c3 * e) * c3; w43 += (c4 * e) * c3; w44 += (c4 * e) * c4;
-      w53 += (c5 * e) * c3; w54 += (c5 * e) * c4; w55 += (c5 * e) * c5;
-    }
-    const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
-    jerk_e = 36.0 * w33 * T1 + 144.0 * w43 * T2 + 192.0 * w44 * T3 + 240.0 * w53 * T3 + 720.0 * w54 * T4 + 720.0 * w55 * T5;
-    jerk_gdT = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
-  }
-  const double jerk_cost = wave_sum(jerk_e);
-  STAMP(C, 3);  // jerk
-
-  // ---- row-lane bookkeeping
-  int rrow[RMAX], rpiece[RMAX], rk[RMAX];
-  bool ract[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) {
-    rrow[r] = lane + 64 * r;
-    ract[r] = rrow[r] < rows;
-    rpiece[r] = rrow[r] / 6;
-    rk[r] = rrow[r] - 6 * rpiece[r];
-  }
-  lds_dp gC = C.gC;
-
-  lds_dp gxy = c_X;                  // [13N][2] positional gradient of each even sample
-  lds_dp pbuf = c_X + 26 * N;        // [15][64] pass buffer (also the per-lane stash around the manipulator block)
-  const int NE = TOPAY_EP * N;       // even samples
-  const int npass = (NE + 63) / 64;
-  double cost_pen = 0.0;             // per-lane partial penalty cost
-  double carryx = 0.0, carryy = 0.0; // XY prefix carried across passes (relative to start)
-  const double wT = STAGE == 1 ? P.s1_time_weight : P.s2_time_weight;
-  const double time_cost = wT * wave_sum(lane < N ? c_Tp[lane] : 0.0);
-  bool skip_body = false;            // early rejection (GradGate): the rest of the sample bodies is not needed
-  double f_skip = 0.0;
-  if (STAGE == 2 && gate.early_ok) {  // smoothness + time alone may already decide (a wild step)
-    const double partial = jerk_cost + time_cost;
-    if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
-      skip_body = true;
-      f_skip = partial;
-    }
-  }
-
-  const double wM = STAGE == 1 ? P.s1_moment_weight : P.s2_moment_weight;
-  const double wA = STAGE == 1 ? P.s1_acc_weight : P.s2_acc_weight;
-  const double wD = STAGE == 1 ? P.s1_domega_weight : P.s2_domega_weight;
-
-  // =========================== sweep 1: forward over even samples ===========================
-  for (int pass = 0; pass < npass; pass++) {
-    const int e = pass * 64 + lane;
-    const bool act = e < NE;
-    const int i = act ? e / TOPAY_EP : N - 1;
-    const int m = act ? e - TOPAY_EP * i : 0;
-    const int j = 2 * m;
-    const double T1 = c_Tp[i];
-    const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
-    // Simpson panel m of piece i: samples j, j+1, j+2 — moma_traj_opt.cpp:1282-1291, 1731-1732
-    double f0x, f0y, Ix = 0.0, Iy = 0.0;
-    xy_integrand(cL, rows, i, j * half, f0x, f0y);
-    if (act && m < TOPAY_K) {
-      double f1x, f1y, f2x, f2y;
-      xy_integrand(cL, rows, i, (j + 1) * half, f1x, f1y);
-      xy_integrand(cL, rows, i, (j + 2) * half, f2x, f2y);
-      Ix = coeff * f0x + 4 * coeff * f1x + coeff * f2x;
-      Iy = coeff * f0y + 4 * coeff * f1y + coeff * f2y;
-    }
-    const double incx = wave_incl_scan(Ix, lane), incy = wave_incl_scan(Iy, lane);
-    const double posx = c_sx + (carryx + (incx - Ix));  // CurrentXY at this even sample
-    const double posy = c_sy + (carryy + (incy - Iy));
-    const double totx = __shfl(incx, 63), toty = __shfl(incy, 63);
-    carryx += totx;
-    carryy += toty;
-    if (act && m == TOPAY_K) {  // piece end: VecTrajFinalXY[i+1] — moma_traj_opt.cpp:1750
-      c_pcs[2 * N + 2 * (i + 1)] = posx;
-      c_pcs[2 * N + 2 * (i + 1) + 1] = posy;
-    }
-
-    double gB[12];
-#pragma unroll
-    for (int v = 0; v < 12; v++) gB[v] = 0.0;
-    double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
-    bool jva = false;
-#ifdef TOPAY_STAMPS
-#endif
-    SUBSTAMP_BEGIN(C);
-    if (!skip_body) {
-      // Wave-uniform condition on purpose: the sample body calls the non-inlined manipulator block, and a call under a
-      // partial EXEC mask is where this kernel family has failed on hardware only (wrong lanes passing `lane == 0`
-      // after the call: state the caller keeps in VGPR lanes / scratch across a divergent call).
-      // Lanes beyond the last sample evaluate the first sample of the last piece and their results are dropped.
-      double cst;
-      sample_body<STAGE, OCC>(C, cL, rows, i, j, e, act, step, half, posx, posy, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
-      if (act) {
-        cost_pen += cst;
-      } else {
-#pragma unroll
-        for (int v = 0; v < 12; v++) gB[v] = 0.0;
-        gdTs = 0.0; gpx = 0.0; gpy = 0.0;
-        jva = false;
-      }
-    }
-    SUBSTAMP_END(C, 12);  // sample body of lane 0
-    if (act && !skip_body) {
-      gxy[2 * e] = gpx;
-      gxy[2 * e + 1] = gpy;
-    }
-    // ---- park the per-sample gradient rows in HBM ([value][sample], coalesced): whether they are needed is only known
-    // once the cost of the whole trajectory is (GradGate)
-    if (act && !skip_body) {
-      glb_dp sb = C.sbuf + e;
-      const int ss = C.sb_stride;
-#pragma unroll
-      for (int v = 0; v < 5; v++) sb[v * ss] = gB[v];
-      sb[5 * ss] = gdTs;
-      if (STAGE == 2) {
-#pragma unroll
-        for (int v = 0; v < 7; v++) sb[(6 + v) * ss] = gB[5 + v];
-        sb[13 * ss] = jva ? 1.0 : 0.0;
-      }
-    }
-    if (STAGE == 2 && gate.early_ok && !skip_body && pass + 1 < npass) {
-      const double partial = jerk_cost + wave_sum(cost_pen) + time_cost;
-      if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
-        skip_body = true;
-        f_skip = partial;
-      }
-    }
-  }
-
-  STAMP(C, 4);  // sweep 1
-  // ---- per-piece terms between the sweeps
-  double cost_piece = 0.0;
-  double chain0x = 0.0, chain0y = 0.0;  // constant added to every chain entry (ALM term)
-  double mt_add_all = 0.0, mt_add_own = 0.0;
-  if (STAGE == 1) {
-    // end-of-piece tracking penalty — moma_traj_opt.cpp:1172-1178
-    lds_sync();
-    if (lane < N) {
-      const double ex = c_pcs[2 * N + 2 * (lane + 1)] - c_init_xy[2 * lane];
-      const double ey = c_pcs[2 * N + 2 * (lane + 1) + 1] - c_init_xy[2 * lane + 1];
-      cost_piece = P.s1_path_pos_weight * (ex * ex + ey * ey);
-      c_pcs[2 * lane] = P.s1_path_pos_weight * 2.0 * ex;
-      c_pcs[2 * lane + 1] = P.s1_path_pos_weight * 2.0 * ey;
-    }
-    lds_sync();
-  } else {
-    // mean-time band — moma_traj_opt.cpp:1752-1769 (bounds hard-coded 0.5 / 2.0, reference quirk)
-    const double Tm = lane < N ? c_Tp[lane] : 0.0;
-    const double avg = wave_sum(Tm) / N;
-    double add_all = 0.0, add_own = 0.0;
-    if (lane < N) {
-      const double wMT = P.s2_mean_time_weight;
-      if (Tm < avg * 0.5) {
-        const double dd = Tm - avg * 0.5;
-        cost_piece += wMT * dd * dd;
-        add_all += wMT * 2.0 * dd * (-0.5 / N);
-        add_own += wMT * 2.0 * dd;
-      }
-      if (Tm > avg * 2.0) {
-        const double dd = Tm - avg * 2.0;
-        cost_piece += wMT * dd * dd;
-        add_all += wMT * 2.0 * dd * (-2.0 / N);
-        add_own += wMT * 2.0 * dd;
-      }
-    }
-    mt_add_all = add_all;   // their dJ/dT part is added in the gradient phase, after the sample rows (same order as
-    mt_add_own = add_own;   // when both were done in one sweep)
-    // ALM end-point term — moma_traj_opt.cpp:1785-1810
-    C.fxe0 = (c_sx + carryx) - c_ex;
-    C.fxe1 = (c_sy + carryy) - c_ey;
-    const double ea = C.fxe0 + c_lam0 / c_rho0, eb = C.fxe1 + c_lam1 / c_rho1;
-    if (lane == 0) cost_piece += 0.5 * (c_rho0 * (ea * ea) + c_rho1 * (eb * eb));
-    chain0x = c_rho0 * ea;
-    chain0y = c_rho1 * eb;
-  }
-  double penalty_cost = wave_sum(cost_pen + cost_piece);
-  // inf/nan in the penalty terms => cost 1e22, zero penalty gradient — moma_traj_opt.cpp:1790-1807
-  const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
-  lds_sync();
-  const double f_total = jerk_cost + (bad ? 1.0e+22 : penalty_cost) + time_cost;
-
-  STAMP(C, 5);  // between sweeps
-  // ---- the cost is known: is the gradient going to be read?  (wave-uniform)
-  if (skip_body) return f_skip;   // certain rejection: a lower bound of the cost that already fails the test
-  if (!gate.needs(f_total)) return f_total;
-
-  // =========================== gradient phase ===========================
-  for (int t = lane; t < 9 * rows; t += 64) gC[t] = 0.0;
-  lds_sync();
-  // row accumulation from the parked per-sample rows, pass by pass in the order of sweep 1
-  for (int pass = 0; pass < npass; pass++) {
-#ifdef TOPAY_STAMPS
-    const long long rnd_t0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    const int e = pass * 64 + lane;
-    const bool act = e < NE;
-    const int i = act ? e / TOPAY_EP : N - 1;
-    const int m = act ? e - TOPAY_EP * i : 0;
-    const int j = 2 * m;
-    const double step = c_Tp[i] / TOPAY_K, half = step / 2.0;
-    double gB[12], gdTs;
-    bool jva = false;
-    {
-      glb_cdp sb = C.sbuf + (act ? e : NE - 1);
-      const int ss = C.sb_stride;
-      double raw[14];
-#pragma unroll
-      for (int v = 0; v < ((STAGE == 2) ? 14 : 6); v++) raw[v] = sb[v * ss];
-#pragma unroll
-      for (int v = 0; v < 5; v++) gB[v] = act ? raw[v] : 0.0;
-      gdTs = act ? raw[5] : 0.0;
-#pragma unroll
-      for (int v = 0; v < 7; v++) gB[5 + v] = (STAGE == 2 && act) ? raw[6 + v] : 0.0;
-      if (STAGE == 2) jva = act && raw[13] != 0.0;
-    }
-    // ---- hand the per-sample gradient rows to the row lanes: theta/s rows (orders 0-2), gdT and, in stage 2, the
-    // order-0 joint rows, in ONE round.  Row lane (piece pi, power k) accumulates over the samples of its piece that
-    // belong to this pass, three at a time with every LDS operand fetched before the arithmetic starts (a single
-    // wave per SIMD has no other way to overlap the LDS latency); sample order and the arithmetic per sample are
-    // unchanged, padding samples of the last chunk are masked.
-    double rbh[RMAX][3] = {};  // hs-powers of each row of this lane (basis_k(k, hs)), also used by the rare round below
-    constexpr int NV = (STAGE == 2) ? 13 : 6;
-#pragma unroll
-    for (int v = 0; v < 5; v++) pbuf[v * 64 + lane] = gB[v];
-    pbuf[5 * 64 + lane] = gdTs;
-    if (STAGE == 2) {
-#pragma unroll
-      for (int v = 0; v < 7; v++) pbuf[(6 + v) * 64 + lane] = gB[5 + v];
-    }
-    lds_sync();
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-      if (ract[r]) {
-        const int pi = rpiece[r];
-        const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-        const double hs = c_Tp[pi] / TOPAY_K / 2.0;
-        double h0, h1, h2;
-        basis_k(rk[r], hs, h0, h1, h2);
-        rbh[r][0] = h0; rbh[r][1] = h1; rbh[r][2] = h2;
-        const int k0 = rk[r], k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
-        double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
-        double aq[7];
-        if (STAGE == 2) {
-#pragma unroll
-          for (int q = 0; q < 7; q++) aq[q] = gC[(2 + q) * rows + rrow[r]];
-        }
-        constexpr int CH = 3;
-        for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
-          double pb[CH][NV], t0[CH], t1[CH], t2[CH];
-#pragma unroll
-          for (int u = 0; u < CH; u++) {
-            const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
-            const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-            lds_cdp pj = c_pw + 12 * mm;  // row of jj = 2 mm
-            t0[u] = pj[k0]; t1[u] = pj[k1]; t2[u] = pj[k2];
-#pragma unroll
-            for (int v = 0; v < NV; v++) pb[u][v] = pbuf[v * 64 + l];
-          }
-#pragma unroll
-          for (int u = 0; u < CH; u++) {
-            const bool ok = c0 + u < e_hi;
-            const double b0 = h0 * t0[u], b1 = h1 * t1[u], b2 = h2 * t2[u];
-            const double i0 = fma(b2, pb[u][2], fma(b1, pb[u][1], b0 * pb[u][0]));
-            const double i1 = fma(b2, pb[u][4], b1 * pb[u][3]);
-            a0 += ok ? i0 : 0.0;
-            a1 += ok ? i1 : 0.0;
-            gt += ok ? pb[u][5] : 0.0;
-            if (STAGE == 2) {
-#pragma unroll
-              for (int q = 0; q < 7; q++) {
-                const double nq = fma(b0, pb[u][6 + q], aq[q]);
-                aq[q] = ok ? nq : aq[q];
-              }
-            }
-          }
-        }
-        gC[0 * rows + rrow[r]] = a0;
-        gC[1 * rows + rrow[r]] = a1;
-        if (STAGE == 2) {
-#pragma unroll
-          for (int q = 0; q < 7; q++) gC[(2 + q) * rows + rrow[r]] = aq[q];
-        }
-        if (rk[r] == 0) c_gdT[pi] += gt;
-      }
-    }
-    lds_sync();
-#ifdef TOPAY_STAMPS
-    if (C.stamps && lane == 0) C.stamps[15] += (long long)__builtin_amdgcn_s_memtime() - rnd_t0_;
-#endif
-    if (STAGE == 2) {
-      // Round C (rare): joint velocity / acceleration gradBeta rows 1 and 2 — moma_traj_opt.cpp:1689, 1703.
-      // Few samples ever trigger these limits, so the flagged lanes are visited one at a time (wave-uniform loop
-      // over the ballot): the lane's 14 values are broadcast and every row lane of its piece adds its own entry.
-      // No two lanes touch the same accumulator, so the result does not depend on timing.
-      {
-        double g1[7], g2[7];
-#pragma unroll
-        for (int q = 0; q < 7; q++) { g1[q] = 0.0; g2[q] = 0.0; }
-        if (act && jva) {
-          Basis B;
-          make_basis(j * half, B);
-          const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
-#pragma unroll
-          for (int q = 0; q < 7; q++) {
-            double a0, a1, a2;
-            poly3(cL, rows, i, 2 + q, B, a0, a1, a2);
-            const double vDq = a1 * a1 - P.joint_vel_limit2[q];
-            const double vD2q = a2 * a2 - P.joint_acc_limit2[q];
-            if (vDq > 0) {
-              double pe, pd;
-              smoothL1(vDq, P.relu_mu, pe, pd);
-              g1[q] = omg * step * P.s2_mani_vel_weight * pd * 2.0 * a1;
-            }
-            if (vD2q > 0) {
-              double pe, pd;
-              smoothL1(vD2q, P.relu_mu, pe, pd);
-              g2[q] = omg * step * P.s2_mani_acc_weight * pd * 2.0 * a2;
-            }
-          }
-        }
-        unsigned long long todo = __ballot(act && jva);
-        while (todo) {
-          const int src = __ffsll(todo) - 1;
-          todo &= todo - 1;
-          const int se = pass * 64 + src;           // flat even-sample index of the flagged lane
-          const int spi = se / TOPAY_EP, smm = se - TOPAY_EP * spi;
-          double b1v[7], b2v[7];
-#pragma unroll
-          for (int q = 0; q < 7; q++) { b1v[q] = readlane_f64(g1[q], src); b2v[q] = readlane_f64(g2[q], src); }
-#pragma unroll
-          for (int r = 0; r < RMAX; r++) {
-            if (ract[r] && rpiece[r] == spi) {
-              const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
-              const double b1 = rbh[r][1] * c_pw[12 * smm + k1], b2 = rbh[r][2] * c_pw[12 * smm + k2];
-#pragma unroll
-              for (int q = 0; q < 7; q++) {
-                double a = gC[(2 + q) * rows + rrow[r]];
-                a = fma(b1, b1v[q], a);
-                a = fma(b2, b2v[q], a);
-                gC[(2 + q) * rows + rrow[r]] = a;
-              }
-            }
-          }
-        }
-        lds_sync();
-      }
-    }
-#ifdef TOPAY_STAMPS
-    if (C.stamps && lane == 0) C.stamps[11] += (long long)__builtin_amdgcn_s_memtime() - rnd_t0_;
-#endif
-  }
-
-  if (STAGE == 2) {  // mean-time band, dJ/dT part — moma_traj_opt.cpp:1752-1769
-    const double all = wave_sum(mt_add_all);
-    if (lane < N) c_gdT[lane] += all + mt_add_own;
-  }
-  lds_sync();
-  // =========================== sweep 2: backward, XY-gradient chain ===========================
-  if (!bad) {
-    double rcarryx = chain0x, rcarryy = chain0y;
-    for (int pass = npass - 1; pass >= 0; pass--) {
-      const int e = pass * 64 + lane;
-      const bool act = e < NE;
-      const int i = act ? e / TOPAY_EP : N - 1;
-      const int m = act ? e - TOPAY_EP * i : 0;
-      const int j = 2 * m;
-      double chx_in, chy_in, chx_ex, chy_ex;  // chain at the even sample / at the odd sample after it
-      if (STAGE == 2) {
-        const double gx = act ? gxy[2 * e] : 0.0, gy = act ? gxy[2 * e + 1] : 0.0;
-        const double sx_ = wave_incl_rscan(gx, lane), sy_ = wave_incl_rscan(gy, lane);
-        chx_in = sx_ + rcarryx; chy_in = sy_ + rcarryy;
-        chx_ex = chx_in - gx;   chy_ex = chy_in - gy;
-        rcarryx += __shfl(sx_, 0);
-        rcarryy += __shfl(sy_, 0);
-      } else {
-        // stage 1: chain of piece i = sum of tracking gradients of pieces > i (head(i*(2K+1)) quirk)
-        double sx_ = 0.0, sy_ = 0.0;
-        for (int ii = i + 1; ii < N; ii++) { sx_ += c_pcs[2 * ii]; sy_ += c_pcs[2 * ii + 1]; }
-        chx_in = chx_ex = sx_;
-        chy_in = chy_ex = sy_;
-      }
-      double v0 = 0, v1 = 0, v2 = 0, v3 = 0, vT = 0;
-      if (act) {
-        const double T1 = c_Tp[i];
-        const double step = T1 / TOPAY_K, half = step / 2.0, coeff = step / 6.0;
-        const int int_6K = TOPAY_K * 6;
-#pragma unroll
-        for (int odd = 0; odd < 2; odd++) {
-          if (odd == 1 && m == TOPAY_K) break;
-          const int jj = j + odd;
-          Basis B;
-          make_basis(jj * half, B);
-          double th0, th1, th2, s0, sd1, sd2;
-          poly3(cL, rows, i, 0, B, th0, th1, th2);
-          poly3(cL, rows, i, 1, B, s0, sd1, sd2);
-          double sn, cn;
-          det_sincos(th0, &sn, &cn);
-          const double alpha = 1.0 / (2 * TOPAY_K) * jj;
-          const double W = odd ? 4.0 : ((jj == 0 || jj == 2 * TOPAY_K) ? 1.0 : 2.0);  // IntegralChainCoeff
-          const double Cx = (odd ? chx_ex : chx_in) * W, Cy = (odd ? chy_ex : chy_in) * W;
-          // Single{X,Y}Grad{CTheta,CArc,T} — moma_traj_opt.cpp:1293-1300 / 1734-1740, x coeff 1744-1748
-          const double aTh = (-sd1 * sn * coeff) * Cx + (sd1 * cn * coeff) * Cy;
-          const double aS = (cn * coeff) * Cx + (sn * coeff) * Cy;
-          const double gTx = (sd2 * cn - sd1 * th1 * sn) * alpha * coeff + sd1 * cn / int_6K;
-          const double gTy = (sd2 * sn + sd1 * th1 * cn) * alpha * coeff + sd1 * sn / int_6K;
-          vT += gTx * Cx + gTy * Cy;
-          if (odd) { v2 = aTh; v3 = aS; } else { v0 = aTh; v1 = aS; }
-        }
-      }
-      pbuf[0 * 64 + lane] = v0; pbuf[1 * 64 + lane] = v1; pbuf[2 * 64 + lane] = v2; pbuf[3 * 64 + lane] = v3;
-      pbuf[4 * 64 + lane] = vT;
-      lds_sync();
-#pragma unroll
-      for (int r = 0; r < RMAX; r++) {
-        if (ract[r]) {
-          const int pi = rpiece[r];
-          const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
-          const double hs = c_Tp[pi] / TOPAY_K / 2.0;
-          double h0, h1, h2;
-          basis_k(rk[r], hs, h0, h1, h2);
-          const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0;
-          double gt = 0.0, a0 = gC[0 * rows + rrow[r]], a1 = gC[1 * rows + rrow[r]];
-          constexpr int CH = 3;  // samples per chunk, operands fetched up front (see sweep 1)
-          for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
-            double pb[CH][5], tb[CH][4];
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-              const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
-              const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
-              lds_cdp pj = c_pw + 12 * mm;  // rows jj = 2 mm (even sample) and 2 mm + 1 (the odd sample after it)
-              tb[u][0] = pj[rk[r]]; tb[u][1] = pj[k1]; tb[u][2] = pj[6 + rk[r]]; tb[u][3] = pj[6 + k1];
-#pragma unroll
-              for (int v = 0; v < 5; v++) pb[u][v] = pbuf[v * 64 + l];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-              const bool ok = c0 + u < e_hi;
-              const double b0 = h0 * tb[u][0], b1 = h1 * tb[u][1];
-              const double o0 = h0 * tb[u][2], o1 = h1 * tb[u][3];
-              const double i0 = fma(o0, pb[u][2], b0 * pb[u][0]);
-              const double i1 = fma(o1, pb[u][3], b1 * pb[u][1]);
-              a0 += ok ? i0 : 0.0;
-              a1 += ok ? i1 : 0.0;
-              gt += ok ? pb[u][4] : 0.0;
-            }
-          }
-          gC[0 * rows + rrow[r]] = a0;
-          gC[1 * rows + rrow[r]] = a1;
-          if (rk[r] == 0) c_gdT[pi] += gt;
-        }
-      }
-      lds_sync();
-    }
-  } else {
-    penalty_cost = 1.0e+22;
-    for (int t = lane; t < 9 * rows; t += 64) gC[t] = 0.0;
-    if (lane < N) c_gdT[lane] = 0.0;
-    lds_sync();
-  }
-
-  STAMP(C, 6);  // sweep 2
-  // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
-  lds_dp band = c_X;
-  lds_dp rdiag = c_X + 13 * rows;
-  lds_dp adj = C.gC;             // [9][rows]: the adjoint solve runs in place on the dJ/dC accumulator
-  // reload of the LU factors, eight loads in flight per lane (a plain strided loop is serialised load by load)
-  for (int t0 = lane; t0 < 14 * rows; t0 += 64 * 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + 64 * u;
-      v[u] = c_lu[t < 14 * rows ? t : 14 * rows - 1];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + 64 * u;
-      if (t < 14 * rows) c_X[t] = v[u];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) {
-    if (ract[r]) {
-      const int pi = rpiece[r], k = rk[r];
-      const double T1 = c_Tp[pi], T2 = c_Tp[N + pi], T3 = c_Tp[2 * N + pi], T4 = c_Tp[3 * N + pi], T5 = c_Tp[4 * N + pi];
-#pragma unroll
-      for (int d = 0; d < 9; d++) {
-        double jg = 0.0;
-        if (k >= 3) {
-          const double c3 = cL[d * rows + 6 * pi + 3], c4 = cL[d * rows + 6 * pi + 4], c5 = cL[d * rows + 6 * pi + 5];
-          const double e = P.energy_weights[d];
-          if (k == 5) jg = 240.0 * c3 * e * T3 + 720.0 * c4 * e * T4 + 1440.0 * c5 * e * T5;
-          else if (k == 4) jg = 144.0 * c3 * e * T2 + 384.0 * c4 * e * T3 + 720.0 * c5 * e * T4;
-          else jg = 72.0 * c3 * e * T1 + 144.0 * c4 * e * T2 + 240.0 * c5 * e * T3;
-        }
-        adj[d * rows + rrow[r]] = jg + gC[d * rows + rrow[r]];
-      }
-    }
-  }
-  lds_sync();
-  {
-    SUBSTAMP_BEGIN(C);
-    if (lane < 9) {  // one lane per column of the 6N x 9 block
-      band_sweep<2>(adj + lane * rows, band, rdiag, rows);  // b(j) /= A(j,j); b(i) -= A(j,i) b(j), i = j+1..j+6
-      band_sweep<3>(adj + lane * rows, band, rdiag, rows);  // b(i) -= A(j,i) b(j), i = j-6..j-1
-    }
-    SUBSTAMP_END(C, 14);  // the two sweeps alone
-  }
-  lds_sync();
-  STAMP(C, 7);  // adjoint solve
-  // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
-  // each row lane forms its row's dot product, partial sums per piece go through rdiag[] (free now)
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) {
-    if (ract[r]) {
-      const int row = rrow[r];
-      // rows 6i+3..6i+8 belong to knot i (i < N-1); the last three rows to the tail condition
-      int pi, br;  // piece whose coefficients are used, B row
-      bool use = true;
-      if (row >= rows - 3) { pi = N - 1; br = 10 + (row - (rows - 3)); }  // B2: 10 vel, 11 acc, 12 jerk
-      else if (row < 3) { use = false; pi = 0; br = 0; }
-      else { pi = (row - 3) / 6; br = (row - 3) - 6 * pi; }
-      double part = 0.0;
-      if (use) {
-        const double T1 = c_Tp[pi], T2 = c_Tp[N + pi], T3 = c_Tp[2 * N + pi], T4 = c_Tp[3 * N + pi];
-#pragma unroll
-        for (int d = 0; d < 9; d++) {
-          lds_cdp c = cL + d * rows + 6 * pi;
-          const double c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-          double b;
-          if (br == 0) b = -(24.0 * c4 + 120.0 * T1 * c5);                    // -snap
-          else if (br == 1) b = -120.0 * c5;                                  // -crackle
-          else if (br == 2 || br == 3 || br == 10) b = -(c1 + 2.0 * T1 * c2 + 3.0 * T2 * c3 + 4.0 * T3 * c4 + 5.0 * T4 * c5);
-          else if (br == 4 || br == 11) b = -(2.0 * c2 + 6.0 * T1 * c3 + 12.0 * T2 * c4 + 20.0 * T3 * c5);
-          else b = -(6.0 * c3 + 24.0 * T1 * c4 + 60.0 * T2 * c5);
-          part += b * adj[d * rows + row];
-        }
-      }
-      rdiag[row] = part;
-    }
-  }
-  lds_sync();
-  double gdT_tot = 0.0;
-  if (lane < N) {
-    const int i = lane;
-    double s = 0.0;
-    if (i < N - 1) { for (int r = 0; r < 6; r++) s += rdiag[6 * i + 3 + r]; }
-    else { for (int r = 0; r < 3; r++) s += rdiag[rows - 3 + r]; }
-    gdT_tot = jerk_gdT + c_gdT[i] + s;
-  }
-  // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948
-  glb_cdp Tau = c_x;
-  glb_cdp Vq = c_x + 3 * N - 1;
-  if (lane < N) c_g[lane] = (gdT_tot + wT) * dTdTau(Tau[lane]);
-  for (int t = lane; t < 9 * (N - 1); t += 64) {
-    const int i = t / 9, d = t - 9 * i;
-    const double gp = adj[d * rows + 6 * i + 5];  // gdP.col(i) = adjGrad.row(6i+5)
-    const int dq = d >= 2 ? d - 2 : 0;            // clamped for the same reason as in minco_generate
-    if (d == 0) c_g[N + i] = gp;
-    else if (d == 1) c_g[2 * N - 1 + i] = gp;
-    else c_g[3 * N - 1 + 7 * i + dq] = gp * dQdVq(Vq[7 * i + dq], P.joint_pos_limit_max[dq]);
-  }
-  if (lane == 0) c_g[3 * N - 2] = adj[1 * rows + rows - 3];  // gradArc[N-1] = gdP_tail(1,0)
-  __syncthreads();  // g (global memory) becomes visible to the lanes that read it next
-  STAMP(C, 8);  // gradient assembly
-  return f_total;
 }
 
 }  // namespace topay

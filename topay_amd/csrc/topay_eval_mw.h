@@ -77,13 +77,24 @@ __device__ __forceinline__ double wg_max(lds_dp red, int& phase, int wave, doubl
   return m;
 }
 
-// LDS of an NW-wave workgroup: coefficients | [adjoint block] | T powers | head/tail | dJ/dT | per-piece scratch | power
-// table | cross-wave scratch | union (band + reciprocal diagonal | positional gradients + one pass buffer per wave)
-#define TOPAY_MW_MISC(NW) (8 + 64 + 2 * (NW) * 64 + 8)
+// LDS of an NW-wave workgroup: coefficients | [adjoint block] | T powers | dJ/dT | per-piece scratch | power table |
+// cross-wave scratch | union (band + reciprocal diagonal | positional gradients + one pass buffer per wave).
+// One wave (round 4): LDS is what decides how many trajectories share a compute unit once the kernels fit two waves per
+// SIMD, so the one-wave plan holds nothing it can do without -- always the compact layout (the adjoint solve runs in the
+// coefficients' block), a pass buffer of 7 rows (the gradient rows of a pass are handed to the row lanes in two halves),
+// no per-round cost exchange (the cost of a pass stays in its lane's register), pass totals sized by the passes there are,
+// and the boundary conditions read from HBM where they are used (once per evaluation): 148 N + 264 doubles for N >= 8,
+// 14 / 20 / 27 / 40 KB at N = 10 / 15 / 21 / 32 (rounds 1-3: 21 / 27 / 36 / 54 KB).
+__host__ __device__ __forceinline__ int mw_pb_rows(int NW) { return NW == 1 ? 7 : 14; }
+__host__ __device__ __forceinline__ int mw_npass(int Nmax) { return (TOPAY_EP * Nmax + 63) / 64; }
+// [8] partial sums of a workgroup reduction (two phases) | [2 npass] pass totals | [2][NW][64] per-round costs (NW > 1) | [8] masks
+__host__ __device__ __forceinline__ int mw_misc_doubles(int Nmax, int NW) {
+  return 8 + 2 * mw_npass(Nmax) + (NW > 1 ? 2 * NW * 64 : 0) + 8;
+}
 __host__ __device__ __forceinline__ int lds_doubles_mw(int Nmax, int NW, int compact) {
   const int rows = 6 * Nmax;
-  const int xr = 14 * rows, sr = 26 * Nmax + 15 * 64 * NW;
-  return 9 * rows * (compact ? 1 : 2) + 5 * Nmax + 54 + Nmax + 4 * (Nmax + 1) + 156 + TOPAY_MW_MISC(NW) + (xr > sr ? xr : sr);
+  const int xr = 14 * rows, sr = 26 * Nmax + mw_pb_rows(NW) * 64 * NW;
+  return 9 * rows * (compact ? 1 : 2) + 5 * Nmax + Nmax + 4 * (Nmax + 1) + 156 + mw_misc_doubles(Nmax, NW) + (xr > sr ? xr : sr);
 }
 __device__ __forceinline__ void carve_mw(EvalCtx& C, lds_dp base, int Nmax, int NW, int compact) {
   const int rows = 6 * Nmax;
@@ -93,13 +104,13 @@ __device__ __forceinline__ void carve_mw(EvalCtx& C, lds_dp base, int Nmax, int 
   else { C.adj = p; p += 9 * rows; }
   C.gC = C.adj;
   C.Tp = p; p += 5 * Nmax;
-  C.hp = p; p += 54;
   C.gdT = p; p += Nmax;
   C.pcs = p; p += 4 * (Nmax + 1);
   C.pw = p; p += 156;
-  C.red = p; p += TOPAY_MW_MISC(NW);
+  C.red = p; p += mw_misc_doubles(Nmax, NW);
   C.X = p;
   C.compact = compact;
+  C.npass_lds = mw_npass(Nmax);
 }
 
 // MINCO generate for an NW-wave workgroup: fills divided over all threads, LU on wave 0 (the pivots are a serial chain),
@@ -110,7 +121,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   const lds_dp c_Tp = C.Tp;
   const lds_dp c_X = C.X;
   const lds_dp c_gdT = C.gdT;
-  const lds_dp c_hp = C.hp;
+  const glb_cdp c_hd = C.hd, c_tl = C.tl;   // head / tail PVA, 9 x 3 col-major each (HBM: read once per evaluation)
   const glb_dp c_lu = C.lu;
   const glb_cdp c_x = C.x;
   const DevParams& P = g_P;
@@ -163,12 +174,12 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   }
   if (tid < 9) {
     const int d = tid;
-    cL[d * rows + 0] = c_hp[0 * 9 + d];
-    cL[d * rows + 1] = c_hp[1 * 9 + d];
-    cL[d * rows + 2] = c_hp[2 * 9 + d];
-    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : c_hp[27 + 0 * 9 + d];
-    cL[d * rows + rows - 2] = c_hp[27 + 1 * 9 + d];
-    cL[d * rows + rows - 1] = c_hp[27 + 2 * 9 + d];
+    cL[d * rows + 0] = c_hd[0 * 9 + d];
+    cL[d * rows + 1] = c_hd[1 * 9 + d];
+    cL[d * rows + 2] = c_hd[2 * 9 + d];
+    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : c_tl[0 * 9 + d];
+    cL[d * rows + rows - 2] = c_tl[1 * 9 + d];
+    cL[d * rows + rows - 1] = c_tl[2 * 9 + d];
   }
   for (int t = tid; t < 9 * (N - 1); t += NT) {
     const int i = t / 9, d = t - 9 * i;
@@ -242,9 +253,11 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const int N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_cdp cL = C.cL;
   int rp = 0;                                  // phase of the workgroup-reduction scratch
-  const lds_dp ptot = c_red + 8;               // [<= 32][2] pass totals of the XY prefix / chain suffix
-  const lds_dp csr = c_red + 8 + 64;           // [2][NW][64] pass costs of one round (two rounds in flight)
-  TOPAY_LDS unsigned long long* jmask = (TOPAY_LDS unsigned long long*)(c_red + 8 + 64 + 2 * NW * 64);   // [NW]
+  const int npl = __builtin_amdgcn_readfirstlane(C.npass_lds);
+  const lds_dp ptot = c_red + 8;               // [npass][2] pass totals of the XY prefix / chain suffix
+  const lds_dp csr = c_red + 8 + 2 * npl;      // [2][NW][64] pass costs of one round (two rounds in flight; NW > 1 only)
+  TOPAY_LDS unsigned long long* jmask = (TOPAY_LDS unsigned long long*)(c_red + 8 + 2 * npl + (NW > 1 ? 2 * NW * 64 : 0));   // [NW]
+  constexpr int PBR = NW == 1 ? 7 : 14;        // rows of a wave's pass buffer
   minco_generate_mw<NW, OCC>(C);
 
   // ---- jerk energy & dJ/dT per piece (thread <-> piece; N <= NT)
@@ -277,8 +290,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   }
 
   lds_dp gxy = c_X;                             // [13N][2] XY prefix of each even sample, then its positional gradient
-  lds_dp pball = c_X + 26 * N;                  // [NW][15][64] one pass buffer per wave
-  lds_dp pbuf = pball + wave * (15 * 64);
+  lds_dp pball = c_X + 26 * N;                  // [NW][PBR][64] one pass buffer per wave
+  lds_dp pbuf = pball + wave * (PBR * 64);
   const int NE = TOPAY_EP * N;
   const int npass = (NE + 63) / 64;
   const int nround = (npass + NW - 1) / NW;
@@ -383,14 +396,17 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
     // the costs of this round's passes, added lane by lane in pass order; early rejection tested after every pass
+    // (one wave: the cost of the round's only pass is this lane's own)
     lds_dp cs = csr + (k & 1) * (NW * 64);
-    cs[wave * 64 + lane] = cst_out;
-    wg_barrier<NW>();
+    if (NW > 1) {
+      cs[wave * 64 + lane] = cst_out;
+      wg_barrier<NW>();
+    }
 #pragma unroll
     for (int q = 0; q < NW; q++) {
       const int p2 = k * NW + q;
       if (p2 < npass) {
-        cost_pen += cs[q * 64 + lane];
+        cost_pen += NW > 1 ? cs[q * 64 + lane] : cst_out;
         if (STAGE == 2 && gate.early_ok && !skip_body && p2 + 1 < npass) {
           const double partial = jerk_cost + wave_sum(cost_pen) + time_cost;
           if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
@@ -406,6 +422,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     carryy += ptot[2 * pc + 1];
     pc++;
   }
+  if (NW == 1) lds_sync();   // (several waves: the barrier of the last round's cost exchange) piece-end positions are read below
 
   // ---- per-piece terms between the sweeps
   double cost_piece = 0.0;
@@ -473,6 +490,161 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     }
   }
   constexpr int NV = (STAGE == 2) ? 13 : 6;
+  if constexpr (NW == 1) {
+    // One wave: a pass's gradient rows reach the row lanes in two halves through the 7-row pass buffer -- theta / s rows
+    // and dJ/dT first, then the seven joint rows.  Every accumulator still sees its samples in ascending order, so the sums
+    // are the sums of the 13-row round; the rare joint velocity / acceleration rows are broadcast from the flagged lanes'
+    // registers (no LDS), sample by sample in ascending order.
+    for (int pass = 0; pass < npass; pass++) {
+      const int e = pass * 64 + lane;
+      const bool act = e < NE;
+      const int i = act ? e / TOPAY_EP : N - 1;
+      const int m = act ? e - TOPAY_EP * i : 0;
+      const int j = 2 * m;
+      const double step = c_Tp[i] / TOPAY_K, half = step / 2.0;
+      bool jva = false;
+      double rawq[7];
+      {
+        glb_cdp sb = C.sbuf + (act ? e : NE - 1);
+        const int ss = C.sb_stride;
+        double raw[14];
+#pragma unroll
+        for (int v = 0; v < ((STAGE == 2) ? 14 : 6); v++) raw[v] = sb[v * ss];
+#pragma unroll
+        for (int v = 0; v < 6; v++) pbuf[v * 64 + lane] = act ? raw[v] : 0.0;
+#pragma unroll
+        for (int v = 0; v < 7; v++) rawq[v] = (STAGE == 2 && act) ? raw[6 + v] : 0.0;
+        if (STAGE == 2) jva = act && raw[13] != 0.0;
+      }
+      lds_sync();
+      // half 1: theta / s rows (orders 0-2 / 1-2) and dJ/dT
+#pragma unroll
+      for (int r = 0; r < RMAX; r++) {
+        if (ract[r]) {
+          const int pi = rpiece[r];
+          const double h0 = rbh[r][0], h1 = rbh[r][1], h2 = rbh[r][2];
+          const int k0 = rk[r], k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
+          const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+          double gt = 0.0;
+          constexpr int CH = 3;
+          for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
+            double pb[CH][6], t0[CH], t1[CH], t2[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+              const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
+              const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+              lds_cdp pj = c_pw + 12 * mm;
+              t0[u] = pj[k0]; t1[u] = pj[k1]; t2[u] = pj[k2];
+#pragma unroll
+              for (int v = 0; v < 6; v++) pb[u][v] = pbuf[v * 64 + l];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+              const bool ok = c0 + u < e_hi;
+              const double b0 = h0 * t0[u], b1 = h1 * t1[u], b2 = h2 * t2[u];
+              const double i0 = fma(b2, pb[u][2], fma(b1, pb[u][1], b0 * pb[u][0]));
+              const double i1 = fma(b2, pb[u][4], b1 * pb[u][3]);
+              a0[r] += ok ? i0 : 0.0;
+              a1[r] += ok ? i1 : 0.0;
+              gt += ok ? pb[u][5] : 0.0;
+            }
+          }
+          if (e_lo < e_hi && rk[r] == 0) c_gdT[pi] += gt;
+        }
+      }
+      if (STAGE == 2) {
+        lds_sync();
+#pragma unroll
+        for (int v = 0; v < 7; v++) pbuf[v * 64 + lane] = rawq[v];
+        lds_sync();
+        // half 2: the order-0 joint rows
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+          if (ract[r]) {
+            const int pi = rpiece[r];
+            const double h0 = rbh[r][0];
+            const int k0 = rk[r];
+            const int e_lo = max(TOPAY_EP * pi, pass * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, pass * 64 + 64), NE);
+            constexpr int CH = 3;
+            for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
+              double pb[CH][7], t0[CH];
+#pragma unroll
+              for (int u = 0; u < CH; u++) {
+                const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
+                const int l = ee - pass * 64, mm = ee - TOPAY_EP * pi;
+                t0[u] = c_pw[12 * mm + k0];
+#pragma unroll
+                for (int v = 0; v < 7; v++) pb[u][v] = pbuf[v * 64 + l];
+              }
+#pragma unroll
+              for (int u = 0; u < CH; u++) {
+                const bool ok = c0 + u < e_hi;
+                const double b0 = h0 * t0[u];
+#pragma unroll
+                for (int qq = 0; qq < 7; qq++) {
+                  const double nq = fma(b0, pb[u][qq], aq[r][qq]);
+                  aq[r][qq] = ok ? nq : aq[r][qq];
+                }
+              }
+            }
+          }
+        }
+        // rare: joint velocity / acceleration gradBeta rows 1 and 2 (moma_traj_opt.cpp:1689, 1703) of the flagged samples
+        unsigned long long todo = __ballot(jva);
+        if (todo != 0) {
+          double g1[7], g2[7];
+#pragma unroll
+          for (int q = 0; q < 7; q++) { g1[q] = 0.0; g2[q] = 0.0; }
+          if (jva) {
+            Basis B;
+            make_basis(j * half, B);
+            const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+              double p0, p1, p2;
+              poly3(cL, rows, i, 2 + q, B, p0, p1, p2);
+              const double vDq = p1 * p1 - P.joint_vel_limit2[q];
+              const double vD2q = p2 * p2 - P.joint_acc_limit2[q];
+              if (vDq > 0) {
+                double pe, pd;
+                smoothL1(vDq, P.relu_mu, pe, pd);
+                g1[q] = omg * step * P.s2_mani_vel_weight * pd * 2.0 * p1;
+              }
+              if (vD2q > 0) {
+                double pe, pd;
+                smoothL1(vD2q, P.relu_mu, pe, pd);
+                g2[q] = omg * step * P.s2_mani_acc_weight * pd * 2.0 * p2;
+              }
+            }
+          }
+          while (todo) {
+            const int src = __ffsll(todo) - 1;
+            todo &= todo - 1;
+            const int se = pass * 64 + src;
+            const int spi = se / TOPAY_EP, smm = se - TOPAY_EP * spi;
+            double b1v[7], b2v[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) { b1v[q] = readlane_f64(g1[q], src); b2v[q] = readlane_f64(g2[q], src); }
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+              if (ract[r] && rpiece[r] == spi) {
+                const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
+                const double b1 = rbh[r][1] * c_pw[12 * smm + k1], b2 = rbh[r][2] * c_pw[12 * smm + k2];
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                  double a = aq[r][q];
+                  a = fma(b1, b1v[q], a);
+                  a = fma(b2, b2v[q], a);
+                  aq[r][q] = a;
+                }
+              }
+            }
+          }
+        }
+      }
+      lds_sync();   // end of the pass: the pass buffer is free again
+    }
+  } else {
   for (int k = 0; k < nround; k++) {
     const int pass = k * NW + wave;
     const int e = pass * 64 + lane;
@@ -512,7 +684,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
           const int p2 = k * NW + q;
           const int e_lo = max(TOPAY_EP * pi, p2 * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, p2 * 64 + 64), NE);
           if (e_lo >= e_hi) continue;
-          lds_cdp pq = pball + q * (15 * 64);
+          lds_cdp pq = pball + q * (PBR * 64);
           double gt = 0.0;
           constexpr int CH = 3;
           for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
@@ -591,7 +763,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
         wg_barrier<NW>();
         for (int q2 = 0; q2 < NW; q2++) {
           unsigned long long todo = jmask[q2];
-          lds_cdp pq = pball + q2 * (15 * 64);
+          lds_cdp pq = pball + q2 * (PBR * 64);
           while (todo) {
             const int src = __ffsll(todo) - 1;
             todo &= todo - 1;
@@ -621,6 +793,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     wg_barrier<NW>();   // end of the round: the pass buffers and the masks are free again
   }
 
+  }
   if (STAGE == 2) {
     const double all = wg_sum<NW>(c_red, rp, wave, mt_add_all);
     if (tid < N) c_gdT[tid] += all + mt_add_own;
@@ -712,7 +885,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
             const int p2 = k * NW + q;
             const int e_lo = max(TOPAY_EP * pi, p2 * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, p2 * 64 + 64), NE);
             if (e_lo >= e_hi) continue;
-            lds_cdp pq = pball + q * (15 * 64);
+            lds_cdp pq = pball + q * (PBR * 64);
             double gt = 0.0;
             constexpr int CH = 3;
             for (int c0 = e_lo; c0 < e_hi; c0 += CH) {

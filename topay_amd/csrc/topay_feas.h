@@ -27,6 +27,10 @@ struct FeasIO {
   long long cap_panels, cap_samples;
   double* report;       // [38]
   int* feasible;        // [2]: printConstraintsSituations, checkFeasible
+  // Counter bumped (verdicts left 0 / 0, nothing sampled) when the scratch cannot hold the trajectory's panels and sample
+  // times: the in-solve gate borrows the candidate's L-BFGS history block, which a small mem_size makes short -- the host
+  // then gates the batch with the separate kernel and scratch of the right size.  Null: scratch sized by the host.
+  int* truncated;
 };
 
 // PolyTrajectory::locatePieceIdx (minco.hpp:356-374): t becomes the local time
@@ -112,7 +116,22 @@ __device__ __forceinline__ void feasibility_gate(const FeasIO& F, const TOPAY_GL
   const int approx_res = 4;
   const double h = seq_res / approx_res, hh = h / 2.0, h6 = h / 6.0;
   long long num = (long long)floor(Ttot / h);
-  if (num > F.cap_panels) num = F.cap_panels;
+  if (num > F.cap_panels || (long long)(Ttot / 0.01) + 2 > F.cap_samples) {
+    // the scratch cannot hold this trajectory: nothing is sampled (a truncated sweep would miss the tail's violations)
+    if (lane == 0) {
+      for (int k = 0; k < 38; k++) F.report[k] = 0.0 / 0.0;
+      F.feasible[0] = 0;
+      F.feasible[1] = 0;
+      if (F.truncated) {
+#ifndef TOPAY_CPU_EMU
+        __hip_atomic_fetch_add(F.truncated, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        F.truncated[0] += 1;
+#endif
+      }
+    }
+    return;
+  }
   if (lane == 0) { F.cseq[0] = F.x0; F.cseq[1] = F.y0; }
   double carryx = 0.0, carryy = 0.0;
   for (long long p0 = 0; p0 < num; p0 += 64) {

@@ -111,14 +111,13 @@ struct ClassDef {
   int max_n, rmax, nw;
   solve_kernel_t solve;
   eval_kernel_t eval;
-  int mwe = 0;   // the evaluation of topay_eval_mw.h (always for nw > 1); with one wave: in its compact LDS layout
-  int occ = 1;   // waves per SIMD the kernel is built for (512 / occ registers per lane)
+  int occ = 2;   // waves per SIMD the kernel is built for (512 / occ registers per lane; every kernel: 256, no AGPRs)
 };
 static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
-        {10, 1, 1, k_solve1, k_eval1, 0, 2}, {15, 2, 1, k_solve2, k_eval2, 0, 2}, {21, 2, 1, k_solve2, k_eval2, 0, 2}, {32, 3, 1, k_solve3, k_eval3, 0, 2},
-        {42, 2, 2, k_solve2w2, k_eval2w2, 0, 2}, {64, 3, 2, k_solve3w2, k_eval3w2, 0, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 0, 2}};
+        {10, 1, 1, k_solve1, k_eval1, 2}, {15, 2, 1, k_solve2, k_eval2, 2}, {21, 2, 1, k_solve2, k_eval2, 2}, {32, 3, 1, k_solve3, k_eval3, 2},
+        {42, 2, 2, k_solve2w2, k_eval2w2, 2}, {64, 3, 2, k_solve3w2, k_eval3w2, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2}};
     // Two waves per trajectory for N = 33..64: measured on one box with three batches in flight (tools/experiments/r3_mw_ab.sh),
     // one / two / four waves for both classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 /
     // 1.03 s.  Four waves halve a long candidate's solve but occupy four SIMD slots for it (the serial parts -- LU,
@@ -126,15 +125,11 @@ static const ClassDef* class_table() {
 #ifdef TOPAY_EXPERIMENTS
     auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     const int w4 = env_nw("TOPAY_MW_C4", 2), w5 = env_nw("TOPAY_MW_C5", 2);
-    if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4, 0, 2};
-    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 0, 2};
-    if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6, 0, 2};
-    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 0, 2};
+    if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4, 2};
+    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 2};
+    if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6, 2};
+    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 2};
 #endif
-    for (int k = 4; k < TOPAY_NBUCKET; k++) t[k].mwe = t[k].nw > 1;
-    // (The templates also instantiate with one wave -- <R, 1, true>: the register-accumulator evaluation in its compact
-    // 138 N-double LDS layout.  Measured for the common classes in round 3: bit-identical results, 1.7 % slower per step,
-    // and no more resident workgroups once the long classes run on several waves; not built.)
     return t;
   }();
   return tab;
@@ -142,12 +137,11 @@ static const ClassDef* class_table() {
 static const int kLdsDoublesPerCU = 160 * 1024 / 8;
 // compact LDS layout (topay_eval_mw.h) when the full one does not fit a compute unit
 static int class_compact(const ClassDef& cd, int nm) {
-  if (!cd.mwe) return 0;
   if (cd.nw == 1) return 1;   // one wave: LDS is what limits how many workgroups share a compute unit
   return lds_doubles_mw(nm, cd.nw, 0) + 8 + 48 > kLdsDoublesPerCU ? 1 : 0;
 }
 static size_t class_lds_bytes(const ClassDef& cd, int nm) {
-  const int d = !cd.mwe ? lds_doubles(nm) : lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
+  const int d = lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
   return (size_t)(d + 8 + 48) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [48]
 }
 
@@ -180,6 +174,12 @@ struct topay_ctx {
   std::vector<MapArena> map_arenas;
   DevBuf dmaps;
   std::vector<char> have_map = std::vector<char>(TOPAY_MAX_MAPS, 0);
+  // topay_share_maps: slot m of this context refers to the fields of map_owner[m] (null: its own); map_sharers = the
+  // contexts that refer to slots of this one.  When the owner refills or frees a slot, the sharers' slots are invalidated
+  // (have_map 0 -> TOPAY_ERR_NO_MAP) after their pending solves have finished: no context keeps a dangling descriptor.
+  std::vector<topay_ctx*> map_owner = std::vector<topay_ctx*>(TOPAY_MAX_MAPS, nullptr);
+  std::vector<topay_ctx*> map_sharers;
+  std::vector<int> h_map_id;   // map slot of every candidate of the resident batch
   // batch
   int B = 0, Nmax = 0, total_states = 0, Pmax = 0;
   // pieces / decision-vector elements of the candidates before b (packed per-candidate blocks, DevBatch::poff / noff)
@@ -214,7 +214,7 @@ struct topay_ctx {
   bool persistent = true;    // solve launches: one workgroup per SIMD slot pulling candidates from a queue
   bool steal = true;         // ... and draining the smaller classes' queues once its own is empty (TOPAY_STEAL=0: profiling)
   int simd_slots = 1024;
-  double occ2_gain = 1.4;    // work per SIMD-second of the two-waves-per-SIMD classes relative to one wave per SIMD (sizes the launches only)
+  double occ2_gain = 1.7;    // work per SIMD-second of the two-waves-per-SIMD classes relative to one wave per SIMD (sizes the launches only)
   DevBuf qnext;
   DevBuf mc_i, mc_d, mc_k, mc_rs, mc_in;   // node tables, Reeds-Shepp words and inputs of the last topay_mcrrt_plan
   int mc_n = 0, mc_node_cap = 0;
@@ -476,9 +476,53 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   return TOPAY_OK;
 }
 
+// The owner is about to refill (or free) slots [first, first + n): every context that shares one of them finishes its
+// pending solve and loses the slot.
+static void invalidate_sharers(topay_ctx* owner, int first, int n) {
+  std::vector<topay_ctx*> sharers;
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    sharers = owner->map_sharers;
+  }
+  for (topay_ctx* s : sharers) {
+    bool hit = false;
+    for (int m = first; m < first + n; m++) hit = hit || s->map_owner[m] == owner;
+    if (!hit) continue;
+    if (s->pending) (void)topay_synchronize(s);
+    for (int m = first; m < first + n; m++)
+      if (s->map_owner[m] == owner) {
+        s->map_owner[m] = nullptr;
+        s->have_map[m] = 0;
+        memset(&s->hmaps[m], 0, sizeof(DevMap));
+        // a resident batch that uses the slot cannot be solved, evaluated or gated any more: it has to be set again
+        if (s->have_traj && std::find(s->h_map_id.begin(), s->h_map_id.end(), m) != s->h_map_id.end()) { s->have_traj = false; s->solved = false; }
+      }
+    bool any = false;
+    for (int m = 0; m < TOPAY_MAX_MAPS; m++) any = any || s->map_owner[m] == owner;
+    if (!any) {
+      std::lock_guard<std::mutex> lk(g_registry_mutex);
+      owner->map_sharers.erase(std::remove(owner->map_sharers.begin(), owner->map_sharers.end(), s), owner->map_sharers.end());
+    }
+  }
+}
+// slots [first, first + n) of c stop referring to another context's fields (c fills them itself, or goes away)
+static void drop_shared_slots(topay_ctx* c, int first, int n) {
+  std::lock_guard<std::mutex> lk(g_registry_mutex);
+  for (int m = first; m < first + n; m++) {
+    topay_ctx* o = c->map_owner[m];
+    if (!o) continue;
+    c->map_owner[m] = nullptr;
+    bool any = false;
+    for (int q = 0; q < TOPAY_MAX_MAPS; q++) any = any || c->map_owner[q] == o;
+    if (!any) o->map_sharers.erase(std::remove(o->map_sharers.begin(), o->map_sharers.end(), c), o->map_sharers.end());
+  }
+}
+
 void topay_destroy(topay_ctx* c) {
   if (!c) return;
   if (c->pending) (void)topay_synchronize(c);
+  invalidate_sharers(c, 0, TOPAY_MAX_MAPS);
+  drop_shared_slots(c, 0, TOPAY_MAX_MAPS);
   {
     std::lock_guard<std::mutex> lk(g_registry_mutex);
     g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
@@ -516,6 +560,9 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // inputs of a solve in flight stay untouched
   const size_t n2 = (size_t)desc->dims[0] * desc->dims[1], n3 = n2 * desc->dims[2];
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
+  if (n3 >= (1ull << 32)) { set_err("map of 2^32 cells or more (the lookups index a field with 32 bits)"); return TOPAY_ERR_UNSUPPORTED; }
+  invalidate_sharers(c, map_id, 1);
+  drop_shared_slots(c, map_id, 1);
   topay_status s;
   if ((s = c->map2d[map_id].ensure(n2 * 8)) != TOPAY_OK) return s;
   if ((s = c->map3d[map_id].ensure(n3 * 8)) != TOPAY_OK) return s;
@@ -549,10 +596,17 @@ extern "C" topay_status topay_share_maps(topay_ctx* c, topay_ctx* owner, int fir
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
   for (int m = first_map_id; m < first_map_id + n_maps; m++)
     if (!owner->have_map[m]) return TOPAY_ERR_NO_MAP;
+  invalidate_sharers(c, first_map_id, n_maps);   // (contexts that shared c's own copies of these slots)
+  drop_shared_slots(c, first_map_id, n_maps);
   for (int m = first_map_id; m < first_map_id + n_maps; m++) {
     c->map2d[m].release(); c->map3d[m].release(); c->map2d_inf[m].release(); c->map2d_crit[m].release();   // own copies of these slots, if any
     c->hmaps[m] = owner->hmaps[m];
     c->have_map[m] = 1;
+    c->map_owner[m] = owner;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    if (std::find(owner->map_sharers.begin(), owner->map_sharers.end(), c) == owner->map_sharers.end()) owner->map_sharers.push_back(c);
   }
   for (size_t i = 0; i < c->map_arenas.size();) {   // arenas of own builds that only held these slots
     topay_ctx::MapArena& a = c->map_arenas[i];
@@ -625,6 +679,9 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   const int nx = desc->dims[0], ny = desc->dims[1], nz = desc->dims[2];
   const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, M = (size_t)n_maps;
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
+  if (n3 >= (1ull << 32)) { set_err("map of 2^32 cells or more (the lookups index a field with 32 bits)"); return TOPAY_ERR_UNSUPPORTED; }
+  invalidate_sharers(c, first_map_id, n_maps);
+  drop_shared_slots(c, first_map_id, n_maps);
   topay_status s;
   if ((s = c->edt_occ.ensure(M * (n3 + 3 * n2))) != TOPAY_OK) return s;   // 3-D, 2-D, 2-D critical, 2-D scratch
   if ((s = c->edt_tmp1.ensure(M * n3 * 8)) != TOPAY_OK) return s;
@@ -874,6 +931,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   }
   c->B = batch;
   c->Pmax = Pmax;
+  c->h_map_id = mids;
   const size_t tot = (size_t)off[batch];
   topay_status s;
 #define ENS(buf, bytes) if ((s = c->buf.ensure(bytes)) != TOPAY_OK) return s
@@ -1226,6 +1284,12 @@ topay_status topay_optimize_async(topay_ctx* c) {
     HIPCHK(hipHostGetDevicePointer(&dp, c->h_cancel, 0));
     c->db.cancel_flag = (const int*)dp;
   }
+  c->h_started[12] = 0;
+  {
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_started + 12, 0));
+    c->db.gate_truncated = (int*)dp;
+  }
   c->db.cancel_budget = c->n_groups > 0 ? c->cancel_budget : 0;
   if (c->n_groups > 0) HIPCHK(hipMemsetAsync(c->group_tau.p, 0x7f, (size_t)c->n_groups * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->interrupted.p, 0, (size_t)c->B * 4, c->stream));
@@ -1251,7 +1315,9 @@ topay_status topay_synchronize(topay_ctx* c) {
     c->last_ms = ms;
     c->solved = true;
     c->pending = false;
-    c->gate_done = c->gate_in_solve;
+    // (a candidate whose history block could not hold the gate's scratch -- a small mem_size -- was left ungated by its
+    // wave: the verdicts are then taken by the separate kernel, with scratch of the right size, at the first request)
+    c->gate_done = c->gate_in_solve && c->h_started[12] == 0;
     if (c->n_groups > 0 && c->cancel_budget > 0) {
       // The rule, applied once more to the finished batch so that the outcome does not depend on WHEN a candidate saw its
       // group's clock: a candidate counts iff its own work clock is within cancel_budget of the smallest clock of a
@@ -1938,15 +2004,15 @@ topay_status topay_get_x(topay_ctx* c, int i, int* n, double* x) {
 
 // Kernel for a forced number of waves per trajectory (test hook topay_eval_waves): the smallest template that holds N.
 static bool class_for_waves(int N, int nw, ClassDef& out) {
-  static const ClassDef w1[] = {{10, 1, 1, nullptr, k_eval1, 0, 2}, {21, 2, 1, nullptr, k_eval2, 0, 2}, {32, 3, 1, nullptr, k_eval3, 0, 2},
-                                {42, 4, 1, nullptr, k_eval4, 0, 2}, {64, 6, 1, nullptr, k_eval6, 0, 2}};
-  static const ClassDef w2[] = {{42, 2, 2, nullptr, k_eval2w2, 0, 2}, {64, 3, 2, nullptr, k_eval3w2, 0, 2}};
-  static const ClassDef w4[] = {{85, 2, 4, nullptr, k_eval2w4, 0, 2}, {TOPAY_MAX_N, 3, 4, nullptr, k_eval3w4, 0, 2}};
+  static const ClassDef w1[] = {{10, 1, 1, nullptr, k_eval1, 2}, {21, 2, 1, nullptr, k_eval2, 2}, {32, 3, 1, nullptr, k_eval3, 2},
+                                {42, 4, 1, nullptr, k_eval4, 2}, {64, 6, 1, nullptr, k_eval6, 2}};
+  static const ClassDef w2[] = {{42, 2, 2, nullptr, k_eval2w2, 2}, {64, 3, 2, nullptr, k_eval3w2, 2}};
+  static const ClassDef w4[] = {{85, 2, 4, nullptr, k_eval2w4, 2}, {TOPAY_MAX_N, 3, 4, nullptr, k_eval3w4, 2}};
   const ClassDef* t = nw == 1 ? w1 : (nw == 2 ? w2 : (nw == 4 ? w4 : nullptr));
   const int cnt = nw == 1 ? 5 : 2;
   if (!t) return false;
   for (int k = 0; k < cnt; k++)
-    if (N <= t[k].max_n) { out = t[k]; out.mwe = out.nw > 1; return true; }
+    if (N <= t[k].max_n) { out = t[k]; return true; }
   return false;
 }
 

@@ -46,12 +46,12 @@ __device__ __forceinline__ long long uniform_i64(long long v) {
 }
 
 // LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
-template <int NW, bool MWE>
+template <int NW>
 __host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds, int compact) {
-  return !MWE ? lds_doubles(Nmax_lds) : lds_doubles_mw(Nmax_lds, NW, compact);
+  return lds_doubles_mw(Nmax_lds, NW, compact);
 }
 
-template <int RMAX, int NW, bool MWE>
+template <int RMAX, int NW>
 __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int compact) {
   constexpr int NT = 64 * NW;
   C.tid = threadIdx.x;
@@ -61,13 +61,10 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
   C.red = nullptr; C.adj = nullptr; C.compact = 0; C.cl_in_lds = 1;
-  if (!MWE) carve(C, TOPAY_LDS_PTR, Nmax_lds);
-  else carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
+  carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
   fill_power_table(C.pw, C.lane);
-  for (int t = C.tid; t < 27; t += NT) {
-    C.hp[t] = Bt.head[(size_t)b * 27 + t];
-    C.hp[27 + t] = Bt.tail[(size_t)b * 27 + t];
-  }
+  C.hd = (glb_cdp)(Bt.head + (size_t)b * 27);
+  C.tl = (glb_cdp)(Bt.tail + (size_t)b * 27);
   const long long po = uniform_i64(Bt.poff[b]);
   C.lu = (glb_dp)(Bt.lu + 84 * po);
   C.sb_stride = TOPAY_EP * C.N;
@@ -105,13 +102,13 @@ __device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& B
 }
 
 // test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
-template <int RMAX, int NW, bool MWE, int OCC>
+template <int RMAX, int NW, int OCC>
 __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int compact, int repeats) {
   const int b = Bt.order[blockIdx.x];
   const bool commit = (stage & 16) != 0;
   stage &= 15;
   EvalCtx C;
-  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   const long long no = uniform_i64(Bt.noff[b]);
   C.x = (glb_cdp)(Bt.x + no);
@@ -126,14 +123,9 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
     GradGate gate;
     gate.always = !cost_only; gate.has_early = false; gate.finit = 0.0; gate.thr = -1.0e300; gate.early = 0.0;
     gate.early_ok = false; gate.skip_thr = 0.0;
-    if constexpr (!MWE) {
-      if (stage == 1) f = eval_cost_grad<1, RMAX, OCC>(C, mp, gate);
-      else f = eval_cost_grad<2, RMAX, OCC>(C, mp, gate);
-    } else {
-      __syncthreads();
-      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
-      else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
-    }
+    __syncthreads();
+    if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
+    else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
   }
   if (C.tid == 0) {
     Bt.fout[b] = f;
@@ -152,7 +144,7 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
 template <int OCC>
 __device__ __noinline__ void feasibility_gate_in_solve(const FeasIO F, const TOPAY_GLB DevMap* mp) { feasibility_gate(F, mp); }
 
-template <int RMAX, int NW, bool MWE, int OCC>
+template <int RMAX, int NW, int OCC>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
   constexpr int NT = 64 * NW;
   const unsigned long long t_begin = wall_clock64();
@@ -166,9 +158,9 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx<RMAX, NW, MWE>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW, MWE>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
   const long long no = uniform_i64(Bt.noff[b]);
   const int n = C.n;
   SolveIO S;
@@ -196,7 +188,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   }
   int success = 0, interrupted = 0;
   double cost = 0.0;
-  solve_trajectory<RMAX, NW, MWE, OCC>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
+  solve_trajectory<RMAX, NW, OCC>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
   // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
   __syncthreads();
   store_result<NW>(C, Bt, b);
@@ -222,6 +214,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
       F.cap_samples = hist_doubles;
       F.report = Bt.feas_report + (size_t)b * 38;
       F.feasible = fl;
+      F.truncated = Bt.gate_truncated;
       feasibility_gate_in_solve<OCC>(F, mp);
       // first feasible success of its planning call: its work clock opens the 100 ms (cancel_budget) window of the others
       if (S.grp_tau && success) {
@@ -258,7 +251,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX, int NW, bool MWE, int OCC>
+template <int RMAX, int NW, int OCC>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int compact, int my_class) {
   const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
@@ -281,7 +274,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX, NW, MWE, OCC>(B, maps, Nmax_lds, compact, B.order[off + pos]);
+      solve_one<RMAX, NW, OCC>(B, maps, Nmax_lds, compact, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -294,47 +287,47 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // length); a resident workgroup that fetches its next candidate itself leaves no slot idle and starts candidates
 // strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
 // not (nothing is shared between candidates).
-template <int RMAX, int NW, bool MWE, int OCC>
+template <int RMAX, int NW, int OCC>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact) {
-  drain_queues<RMAX, NW, MWE, OCC>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
+  drain_queues<RMAX, NW, OCC>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
 // One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32, built for two waves per SIMD (256 registers, no
 // AGPRs: besides the occupancy, this keeps the register allocator from parking values in AGPRs across the calls, the
 // copies this image's compiler misplaces -- tools/isa_lint.py).  Several waves per trajectory (topay_eval_mw.h):
 // k_solve<rows per thread>w<waves>, rows <= 64 x waves x rows per thread, one wave per SIMD.
-#define TOPAY_SOLVE_KERNEL(NAME, R, W, M, OCC)                                                                      \
+#define TOPAY_SOLVE_KERNEL(NAME, R, W, OCC)                                                                         \
   __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds, int compact) { \
-    solve_body<R, W, M, OCC>(Bt, maps, Nmax_lds, compact);                                                          \
+    solve_body<R, W, OCC>(Bt, maps, Nmax_lds, compact);                                                             \
   }
-#define TOPAY_EVAL_KERNEL(NAME, R, W, M, OCC)                                                                       \
+#define TOPAY_EVAL_KERNEL(NAME, R, W, OCC)                                                                          \
   __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds, int compact) { \
-    eval_body<R, W, M, OCC>(Bt, maps, stage, Nmax_lds, compact, repeats);                                           \
+    eval_body<R, W, OCC>(Bt, maps, stage, Nmax_lds, compact, repeats);                                              \
   }
 #ifndef TOPAY_NO_KERNEL_TABLE   // (tools: a probe that instantiates one kernel of its own)
-TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, false, 2)
-TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, false, 2)
-TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, false, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, true, 2)
-TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, true, 2)
-TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, true, 2)
-TOPAY_EVAL_KERNEL(k_eval1, 1, 1, false, 2)
-TOPAY_EVAL_KERNEL(k_eval2, 2, 1, false, 2)
-TOPAY_EVAL_KERNEL(k_eval3, 3, 1, false, 2)
-TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2, true, 2)
-TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2, true, 2)
-TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4, true, 2)
+TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, 2)
+TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, 2)
+TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, 2)
+TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, 2)
+TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, 2)
+TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, 2)
+TOPAY_EVAL_KERNEL(k_eval1, 1, 1, 2)
+TOPAY_EVAL_KERNEL(k_eval2, 2, 1, 2)
+TOPAY_EVAL_KERNEL(k_eval3, 3, 1, 2)
+TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2, 2)
+TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2, 2)
+TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4, 2)
 // evaluation only (test hook topay_eval_waves: one wave for N = 33..64, four waves for N <= 85 -- the references of the
 // order-identity tests of the several-waves evaluation)
-TOPAY_EVAL_KERNEL(k_eval4, 4, 1, false, 2)
-TOPAY_EVAL_KERNEL(k_eval6, 6, 1, false, 2)
-TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, true, 2)
+TOPAY_EVAL_KERNEL(k_eval4, 4, 1, 2)
+TOPAY_EVAL_KERNEL(k_eval6, 6, 1, 2)
+TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, 2)
 #ifdef TOPAY_EXPERIMENTS
 // A/B variants (tools/ab_lib.sh builds with -DTOPAY_EXPERIMENTS): the one-wave kernels of the long classes and four waves
 // for N <= 64
-TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, false, 2)
-TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, false, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, true, 2)
+TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, 2)
+TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, 2)
+TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
 #endif
 #endif  // TOPAY_NO_KERNEL_TABLE
 
@@ -358,6 +351,7 @@ __global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps
   F.cap_panels = cap_panels; F.cap_samples = cap_samples;
   F.report = report + (size_t)b * 38;
   F.feasible = flags + 2 * b;
+  F.truncated = nullptr;
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   feasibility_gate(F, mp);
 }
@@ -390,6 +384,7 @@ __global__ void __launch_bounds__(64) k_playback(DevBatch Bt, int b, double* cse
   F.cap_panels = cap_panels; F.cap_samples = 0;
   F.report = nullptr;
   F.feasible = nullptr;
+  F.truncated = nullptr;
   playback(F, nq, times, states, seq_out, nseq_out);
 }
 

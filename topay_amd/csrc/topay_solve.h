@@ -54,15 +54,29 @@ typedef TOPAY_GLB dpair* glb_pp;
 // thread tid owning the pairs NT p + tid)
 template <int NT = 64>
 __device__ __forceinline__ bool vec_in(int tid, int t, int n) { return 2 * (NT * (t >> 1) + tid) < n; }
+// Pair i (elements 2 i, 2 i + 1) of an n-element row (n even, 16-byte aligned): a raw BUFFER load whose descriptor ends at
+// the row's n-th element, so pairs beyond the row come back as zeros from the hardware's range check -- no index clamp
+// and no select per loaded value (the two-loop recursion is bound by instruction issue: 8 of its 48 vector instructions
+// per history pair were such selects).  The descriptor lives in scalar registers (uniform base).
+__device__ __forceinline__ dpair row_pair_or_zero(glb_cdp row, int n, int i) {
+#ifndef TOPAY_CPU_EMU
+  typedef unsigned int u32x4 __attribute__((vector_size(16)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, n * 8, 0x00020000);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 0);
+  return __builtin_bit_cast(dpair, v);
+#else
+  dpair q;
+  q[0] = 2 * i < n ? row[2 * i] : 0.0;
+  q[1] = 2 * i < n ? row[2 * i + 1] : 0.0;
+  return q;
+#endif
+}
 template <int EPL, int NT = 64>
 __device__ __forceinline__ void vec_load(glb_cdp a, int n, int tid, double (&v)[EPL]) {
   static_assert(EPL % 2 == 0, "pairs");
-  const glb_cpp ap = (glb_cpp)a;
-  const int last = (n >> 1) - 1;
 #pragma unroll
   for (int p = 0; p < EPL / 2; p++) {
-    const int i = NT * p + tid;
-    const dpair q = ap[i <= last ? i : last];
+    const dpair q = row_pair_or_zero(a, n, NT * p + tid);   // (pairs beyond n: zeros; every user masks them anyway)
     v[2 * p] = q[0];
     v[2 * p + 1] = q[1];
   }
@@ -91,7 +105,7 @@ __device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int 
   return s;
 }
 
-template <int RMAX, int NW = 1, bool MWE = (NW > 1), int OCC = 1>
+template <int RMAX, int NW = 1, int OCC = 2>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
                                                  lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out, int& interrupted_out) {
   const DevParams& P = g_P;
@@ -203,15 +217,10 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       qk[9] = (unsigned long long)S.stats; qk[10] = (unsigned long long)S.trace; qk[11] = (unsigned long long)mp;
       qk[12] = (unsigned long long)S.grp_tau; qk[13] = (unsigned long long)S.cancel_flag;
     }
-    if constexpr (!MWE) {
-      if (stage == 1) f = eval_cost_grad<1, RMAX, OCC>(C, mp, gate);
-      else f = eval_cost_grad<2, RMAX, OCC>(C, mp, gate);
-    } else {
-      if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
-      else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
-      if (NW > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
-      rp = 0;
-    }
+    if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
+    else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
+    if (NW > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
+    rp = 0;
     {
       // (read back as wave-uniform values: scalar registers, scalar branches, scalar base addresses for the vector loads)
       lds_cdp pk = pf + 8;
@@ -430,18 +439,16 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             const int endu = __builtin_amdgcn_readfirstlane(end), boundu = __builtin_amdgcn_readfirstlane(bound);
             const int memu = __builtin_amdgcn_readfirstlane(mem), nstr = __builtin_amdgcn_readfirstlane(S.nstride);
             auto load_pair = [&](int slot, int jj) {
-              const glb_cpp sj = (glb_cpp)(S.hist_s + (size_t)jj * nstr);
-              const glb_cpp yj = (glb_cpp)(S.hist_y + (size_t)jj * nstr);
-              const int last = (n >> 1) - 1;
+              const glb_cdp sj = S.hist_s + (size_t)jj * nstr;
+              const glb_cdp yj = S.hist_y + (size_t)jj * nstr;
 #pragma unroll
               for (int p = 0; p < EPL / 2; p++) {
                 const int i = NT * p + tid;
-                const bool in = i <= last;
-                const dpair sv = sj[in ? i : last], yv = yj[in ? i : last];
-                sb[slot][2 * p] = in ? sv[0] : 0.0;
-                sb[slot][2 * p + 1] = in ? sv[1] : 0.0;
-                yb[slot][2 * p] = in ? yv[0] : 0.0;
-                yb[slot][2 * p + 1] = in ? yv[1] : 0.0;
+                const dpair sv = row_pair_or_zero(sj, n, i), yv = row_pair_or_zero(yj, n, i);   // zeros beyond the row
+                sb[slot][2 * p] = sv[0];
+                sb[slot][2 * p + 1] = sv[1];
+                yb[slot][2 * p] = yv[0];
+                yb[slot][2 * p + 1] = yv[1];
               }
               rb[slot] = S.hist_ys[jj];
             };

@@ -141,6 +141,7 @@ struct DevBatch {
   // feasibility gate inside the solve (printConstraintsSituations of the returned trajectory by the wave that solved it;
   // its scratch is the candidate's own, by then dead, L-BFGS history block): verdicts and extremes per candidate
   int gate_in_solve;
+  int* gate_truncated; // one counter in pinned host memory: candidates whose history block was too short for the gate's scratch
   int* feas_flags;    // [B][2]
   double* feas_report;// [B][38]
   // Cancellation (planner.cpp:943-952: the candidates of one planning call that are still running 100 ms after the first
