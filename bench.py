@@ -110,13 +110,22 @@ def main():
     # TOPAY_FORCE_DIST=1: take the multi-rank code path (RCCL init, record gather, reductions) with a single rank too,
     # so that it can be validated on a one-GPU box
     distributed = world > 1 or (os.environ.get("TOPAY_FORCE_DIST") == "1" and "RANK" in os.environ)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (more ranks than devices: the ranks share the devices there are -- how the rank-indexed code is exercised with
+    # WORLD_SIZE 2 on a one-GPU box, tests/test_sharding.py; on a full node local_rank < device_count and nothing changes)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # TOPAY_DIST_BACKEND=gloo: the record exchange over gloo with host tensors (two ranks on ONE device cannot form an RCCL
+    # communicator); default nccl == RCCL on ROCm
+    backend = os.environ.get("TOPAY_DIST_BACKEND", "nccl")
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from topay_amd import api, dist as tdist
     from harness import workload as wl
@@ -157,7 +166,7 @@ def main():
     map_ids_of = {}
     edt_ms = None
     for _ in range(depth):
-        o_ = api.MomaTrajOptBatch(device=local_rank)
+        o_ = api.MomaTrajOptBatch(device=dev_index)
         slot = {s: k for k, s in enumerate(tb.scenarios)}
         if opts and not args.own_maps:
             # the batches in flight share one resident copy of the maps (the reference's optimisers share one GridMap::Ptr)
@@ -232,6 +241,7 @@ def main():
         same = got.shape == ref.shape and bool(np.all((got == ref) | (np.isnan(got) & np.isnan(ref))))
         gather_stats["gathers"] += 1
         gather_stats["rows"] = int(rows.shape[0])
+        gather_stats["distinct_ids"] = int(len(np.unique(rows[:, 0])))
         gather_stats["own_rows_match"] = gather_stats["own_rows_match"] and same
 
     def finish(o_):
@@ -252,7 +262,7 @@ def main():
             tc = time.perf_counter()
             # the exchange of step i is started here and collected while step i+1's records are being prepared: the RCCL
             # kernel has to find a compute unit on a device whose SIMDs all hold resident solver waves of the next batch
-            gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev))
+            gathers.append(tdist.gather_records_begin(recs, max_rows=S, device=dev if backend == "nccl" else None))
             sent.append(recs)
             while len(gathers) > 1:
                 check_gather(tdist.gather_records_end(gathers.pop(0)))
@@ -329,13 +339,24 @@ def main():
                    "trajectories_per_s_per_gpu": (B - n_not_launched) / (tpe / np_),
                    "cancel_window": "2400 piece-evaluations after a scenario's first accepted candidate (= the reference's 100 ms at 42 us per piece-evaluation)",
                    "interrupted_fraction": float(intr.mean()), "scenarios_with_a_trajectory": int(solved_scen)}
+    rank_report = None
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else None
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tot = torch.tensor([float(B - n_not_launched)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(B - n_not_launched)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_traj = float(tot.item())
+        # what every rank worked on (rank-indexed quantities, for the two-ranks-on-one-device test): its scenario ids, a
+        # checksum of its init paths (different seeds -> different inputs) and its share of the solved candidates
+        import hashlib
+        mine = {"rank": rank, "device": dev_index, "scenario_id_min": int(scen_ids.min()), "scenario_id_max": int(scen_ids.max()),
+                "n_scenarios": int(len(scen_ids)), "input_sha": hashlib.sha256(tb.paths.tobytes()).hexdigest()[:16],
+                "solved": int(B - n_not_launched), "success_fraction": float(ok.mean())}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        rank_report = allr
     else:
         total_traj = float(B - n_not_launched)   # only candidates the device actually solved count
 
@@ -344,7 +365,7 @@ def main():
     cfg1 = None
     if rank == 0 and not hires and not args.no_config1:
         w1, _, _, lens1, paths1 = wl.tables_scenario(0, 64)
-        o1 = api.MomaTrajOptBatch(device=local_rank)
+        o1 = api.MomaTrajOptBatch(device=dev_index)
         o1.set_map(w1.origin, w1.res, w1.dims, w1.min_b, w1.max_b, w1.esdf2d, w1.esdf3d)
         o1.set_init_traj(lens1, paths1)
         o1.optimize()
@@ -355,7 +376,7 @@ def main():
                 "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
         o1.close()
         w1.close()
-    simd_slots = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+    simd_slots = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
     gate_timeouts = int(sum(o_.gate_timeouts() for o_ in opts))
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
@@ -420,8 +441,10 @@ def main():
             "h2d_bytes_per_step": int(tb.paths.nbytes + tb.lens.nbytes + 4 * B),
             "winners_per_step": int(winners.get("n", 0)),
             "d2h_winner_bytes_per_step": int(sum(v.nbytes for v in winners["last"].values())) if "last" in winners else 0,
-            "record_gather": (dict(gather_stats, collective="RCCL all-gather of 6 x f64 per scenario", rows_expected=int(S * world))
+            "record_gather": (dict(gather_stats, collective=("RCCL" if backend == "nccl" else backend) + " all-gather of 6 x f64 per scenario",
+                                   rows_expected=int(S * world), scenario_ids_distinct=int(gather_stats.get("distinct_ids", 0)))
                               if distributed else None),
+            "ranks": rank_report,
             "setup_seconds_untimed": setup_s,
             "esdf_build_ms_gpu_untimed": edt_ms,
             "config1_latency": cfg1,

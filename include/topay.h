@@ -471,6 +471,12 @@ topay_status topay_scenario_records(topay_ctx* ctx, const int* scenario_of, int 
 /* ncclAllGather of per_rank records from every rank (n_mine <= per_rank valid ones); all[world x per_rank] receives them
  * in rank order with the valid ones compacted to the front, *n_valid their number.  Runs on a stream of its own. */
 topay_status topay_gather_records(topay_ctx* ctx, const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* all, int* n_valid);
+/* The two halves of that exchange for a caller with a transport of its own (MPI, gloo, a ROS topic): the block a rank
+ * contributes -- its n_mine records padded to per_rank entries with scenario_id = INT32_MIN -- and the reading of the
+ * world x per_rank gathered entries: valid records compacted to the front of `all` in rank order, *n_valid their number,
+ * the rest of `all` padding.  topay_gather_records is pack, ncclAllGather, unpack.  No device is touched. */
+topay_status topay_pack_records(const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* block);
+topay_status topay_unpack_records(const topay_record_t* gathered, int world, int per_rank, topay_record_t* all, int* n_valid);
 
 /* Launch class of a candidate with n_pieces pieces: waves per trajectory (1, 2 or 4) and decision-vector elements per
  * thread of the kernel that solves and (topay_eval) evaluates it.  For parity tooling: the rounding of the solver's dot

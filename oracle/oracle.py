@@ -297,6 +297,32 @@ def optimize_batch_maps(maps, map_id, path_len, paths, nthreads=1, gate=False):
     return out
 
 
+def stage1_batch_maps(maps, map_id, path_len, paths, nthreads=1, xstride=10 * 128 - 8):
+    """Stage 1 alone for a batch (the ALM loop is not entered): converged x per candidate (rows of xstride), cost, counters."""
+    L = lib()
+    M = len(maps)
+    origin = np.ascontiguousarray(np.stack([m.origin for m in maps]), dtype=np.float64)
+    res = np.ascontiguousarray([m.res for m in maps], dtype=np.float64)
+    dims = np.ascontiguousarray(np.stack([m.dims for m in maps]), dtype=np.int32)
+    mn = np.ascontiguousarray(np.stack([m.min_b for m in maps]), dtype=np.float64)
+    mx = np.ascontiguousarray(np.stack([m.max_b for m in maps]), dtype=np.float64)
+    P = C.POINTER(C.c_double)
+    e2 = (P * M)(*[_dp(m.esdf2d) for m in maps])
+    e3 = (P * M)(*[_dp(m.esdf3d) for m in maps])
+    map_id = np.ascontiguousarray(map_id, dtype=np.int32)
+    path_len = np.ascontiguousarray(path_len, dtype=np.int32)
+    paths = np.ascontiguousarray(paths, dtype=np.float64)
+    B = len(path_len)
+    x = np.zeros((B, xstride))
+    cost = np.zeros(B)
+    npc = np.zeros(B, dtype=np.int32)
+    stats = np.zeros(B * 3, dtype=np.int32)
+    L.orc_stage1_batch_maps.restype = C.c_double
+    secs = L.orc_stage1_batch_maps(M, _dp(origin), _dp(res), _ip(dims), _dp(mn), _dp(mx), e2, e3, _ip(map_id), B, _ip(path_len),
+                                   _dp(paths), nthreads, xstride, _dp(x), _dp(cost), _ip(npc), _ip(stats))
+    return dict(x=x, cost=cost, n_pieces=npc, stats=stats.reshape(B, 3), seconds=secs)
+
+
 def group_cancel(group_id, clock, accepted, budget=2400):
     """The planner's cancellation rule (planner.cpp:829-952) on work clocks: bool array, True = interrupted."""
     L = lib()

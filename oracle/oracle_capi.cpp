@@ -247,6 +247,44 @@ double orc_optimize_batch(const double origin[3], double res, const int dims[3],
 
 // Same, but every trajectory names its own map (benchmark_tables batch: one map per scenario).  One pool of
 // nthreads workers over all trajectories.  Map descriptors are arrays of length n_maps.
+// Stage 1 alone (optimizeTraj:359-374: the first L-BFGS run; the ALM loop is not entered) for a batch against per-candidate
+// maps: converged decision vectors x (row b: 10 N_b - 8 entries of a row of `xstride`), stage-1 cost and counters.  Stage 1
+// is short and not chaotic, so this is where a converged result can be compared value by value with the device's.
+double orc_stage1_batch_maps(int n_maps, const double* origin, const double* res, const int* dims, const double* min_b,
+                             const double* max_b, const double* const* esdf2d, const double* const* esdf3d, const int* map_id,
+                             int batch, const int* path_len, const double* paths, int nthreads, int xstride, double* xout,
+                             double* cost, int* n_pieces, int* stats /*[batch][3]: return code, iterations, evaluations*/) {
+  std::vector<size_t> offs(batch + 1, 0);
+  for (int b = 0; b < batch; b++) offs[b + 1] = offs[b] + (size_t)path_len[b] * 10;
+  std::vector<double> zeros(20, 0.0);
+  std::atomic<int> next(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto worker = [&]() {
+    OracleHandle h;
+    h.opt.map = &h.map;
+    h.opt.prm.alm_max_outer = 0;
+    while (true) {
+      int b = next.fetch_add(1);
+      if (b >= batch) break;
+      const int m = map_id[b];
+      if (m < 0 || m >= n_maps) { n_pieces[b] = 0; continue; }
+      h.map.set(origin + 3 * m, res[m], dims + 3 * m, esdf2d[m], esdf3d[m]);
+      h.map.setBounds(min_b + 3 * m, max_b + 3 * m);
+      h.opt.setInitTraj(paths + offs[b], path_len[b], zeros.data(), zeros.data());
+      (void)h.opt.optimize();
+      n_pieces[b] = h.opt.piece_num;
+      cost[b] = h.opt.traj_cost;
+      stats[3 * b] = h.opt.stats.stage1_ret; stats[3 * b + 1] = h.opt.stats.stage1_iters; stats[3 * b + 2] = h.opt.stats.stage1_evals;
+      const int n = (int)h.opt.x.size();
+      for (int k = 0; k < n && k < xstride; k++) xout[(size_t)b * xstride + k] = h.opt.x[k];
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < std::max(1, nthreads); t++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 double orc_optimize_batch_maps(int n_maps, const double* origin /*[M][3]*/, const double* res /*[M]*/,
                                const int* dims /*[M][3]*/, const double* min_b, const double* max_b,
                                const double* const* esdf2d, const double* const* esdf3d, const int* map_id, int batch,

@@ -65,3 +65,91 @@ def test_two_rank_gather(tmp_path):
             best = ok[np.argmin(ref["dur"][s][ok])]
             assert int(row[1]) == best and row[2] == 1 and np.isclose(row[5], ref["dur"][s][best])
             assert np.isclose(row[4], ref["cost"][s][best])
+
+
+WORKER_CABI = r'''
+import os, sys
+sys.path.insert(0, os.environ["TOPAY_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from topay_amd import api
+LIB = os.environ["TOPAY_TEST_LIB"]
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+# unequal counts: rank 0 holds 3 records, rank 1 holds 5; blocks of per_rank = 5 entries
+n_mine = 3 if rank == 0 else 5
+per_rank = 5
+recs = np.zeros(n_mine, dtype=np.dtype(api.Record))
+recs["scenario_id"] = 100 * rank + np.arange(n_mine)
+recs["best_candidate"] = np.arange(n_mine) % 3 - 1
+recs["status"] = (recs["best_candidate"] >= 0).astype(np.int32)
+recs["n_pieces"] = 4 + np.arange(n_mine)
+recs["cost"] = 10.0 * rank + np.arange(n_mine)
+recs["duration"] = 5.5 + rank
+block = api.pack_records(recs, per_rank, lib=LIB)
+assert len(block) == per_rank and (block["scenario_id"][n_mine:] == -2**31).all() and (block["best_candidate"][n_mine:] == -1).all()
+mine = torch.from_numpy(block.view(np.uint8).copy())
+out = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(out, mine)
+gathered = np.concatenate([o.numpy() for o in out]).view(np.dtype(api.Record))
+allr = api.unpack_records(gathered, world, per_rank, lib=LIB)
+if rank == 1:
+    np.save(os.environ["OUT"], allr.view(np.uint8))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_record_blocks_with_unequal_counts_over_two_ranks(tmp_path):
+    """topay_pack_records / topay_unpack_records (the padding with scenario_id = INT32_MIN and the compaction + n_valid
+    that topay_gather_records wraps around ncclAllGather), with a different number of records on each of two ranks and
+    gloo as the transport: every valid record arrives once, in rank order, and nothing of the padding does."""
+    from conftest import EMU_LIB
+    from topay_amd import api
+    out = str(tmp_path / "recs.npy")
+    script = tmp_path / "worker_cabi.py"
+    script.write_text(WORKER_CABI)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OUT=out,
+                   TOPAY_ROOT=ROOT, TOPAY_TEST_LIB=EMU_LIB)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    recs = np.load(out).view(np.dtype(api.Record))
+    assert len(recs) == 8
+    assert recs["scenario_id"].tolist() == [0, 1, 2, 100, 101, 102, 103, 104]
+    assert recs["duration"].tolist() == [5.5] * 3 + [6.5] * 5 and recs["n_pieces"].tolist() == [4, 5, 6, 4, 5, 6, 7, 8]
+    # argument checks
+    import pytest
+    with pytest.raises(api.TopayError):
+        api.pack_records(recs, 4, lib=EMU_LIB)          # more records than the block holds
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_on_the_one_gpu():
+    """BASELINE configs[3]'s rank-indexed code -- seed offsets, global scenario ids, rows_expected, first_instance -- has
+    only ever seen rank 0 on hardware.  Two ranks under torch.distributed.run on device 0 (the launcher is started before
+    anything touches the GPU in that process tree), the record exchange over gloo with host tensors (two ranks on one
+    device cannot form an RCCL communicator): 2 x 64 scenarios, all 128 records on every rank, disjoint id ranges,
+    different inputs per rank."""
+    import json
+
+    env = dict(os.environ, TOPAY_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scenarios", "64",
+           "--no-cpu-baseline", "--no-config1", "--no-serial", "--no-planner"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    g = out["config"]["record_gather"]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["n_not_launched"] == 0
+    assert g["own_rows_match"] is True and g["rows"] == 128 == g["rows_expected"] and g["scenario_ids_distinct"] == 128
+    ranks = sorted(out["config"]["ranks"], key=lambda q: q["rank"])
+    assert [q["rank"] for q in ranks] == [0, 1] and all(q["device"] == 0 for q in ranks)
+    assert (ranks[0]["scenario_id_min"], ranks[0]["scenario_id_max"]) == (0, 63)
+    assert (ranks[1]["scenario_id_min"], ranks[1]["scenario_id_max"]) == (64, 127)
+    assert ranks[0]["input_sha"] != ranks[1]["input_sha"]          # different seeds per rank
+    assert ranks[0]["solved"] == ranks[1]["solved"] == 512

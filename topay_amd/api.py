@@ -272,6 +272,28 @@ def params_from_yaml_c(source, base=None, lib=None):
     return p, ([x for x in ign.split("\n") if x] if ign else [])
 
 
+def pack_records(records, per_rank, lib=None):
+    """A rank's block of the record exchange (topay_pack_records): its records padded to per_rank entries whose
+    scenario_id is INT32_MIN.  No device involved."""
+    L = load(lib)
+    rec = np.ascontiguousarray(records)
+    out = (Record * per_rank)()
+    L.topay_pack_records.argtypes = [C.POINTER(Record), C.c_int, C.c_int, C.POINTER(Record)]
+    _chk(L, L.topay_pack_records(rec.ctypes.data_as(C.POINTER(Record)), len(rec), per_rank, out))
+    return np.ctypeslib.as_array(out).copy()
+
+
+def unpack_records(gathered, world, per_rank, lib=None):
+    """The valid records of world x per_rank gathered entries, in rank order (topay_unpack_records)."""
+    L = load(lib)
+    g = np.ascontiguousarray(gathered)
+    out = (Record * (per_rank * world))()
+    nv = C.c_int(0)
+    L.topay_unpack_records.argtypes = [C.POINTER(Record), C.c_int, C.c_int, C.POINTER(Record), C.POINTER(C.c_int)]
+    _chk(L, L.topay_unpack_records(g.ctypes.data_as(C.POINTER(Record)), world, per_rank, out, C.byref(nv)))
+    return np.ctypeslib.as_array(out)[:nv.value].copy()
+
+
 def _chk(L, status):
     if status != 0:
         raise TopayError(f"topay status {status}: {L.topay_last_error().decode()}")

@@ -2312,6 +2312,31 @@ topay_status topay_scenario_records(topay_ctx* c, const int* scenario_of, int ca
 
 // ncclAllGather of `per_rank` records from every rank (fewer valid ones are padded with scenario_id = INT_MIN); `all`
 // receives world x per_rank records in rank order, *n_valid the number that are not padding (compacted to the front).
+static void record_padding(topay_record_t& r) {
+  r.scenario_id = INT32_MIN; r.best_candidate = -1; r.status = 0; r.n_pieces = 0; r.cost = 0.0; r.duration = 0.0;
+}
+topay_status topay_pack_records(const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* block) {
+  if (n_mine < 0 || per_rank <= 0 || n_mine > per_rank || (n_mine > 0 && !mine) || !block) return TOPAY_ERR_INVALID_ARG;
+  for (int r = 0; r < per_rank; r++) {
+    if (r < n_mine) block[r] = mine[r];
+    else record_padding(block[r]);
+  }
+  return TOPAY_OK;
+}
+topay_status topay_unpack_records(const topay_record_t* gathered, int world, int per_rank, topay_record_t* all, int* n_valid) {
+  if (!gathered || !all || world <= 0 || per_rank <= 0) return TOPAY_ERR_INVALID_ARG;
+  const size_t tot = (size_t)world * per_rank;
+  size_t n = 0;
+  for (size_t k = 0; k < tot; k++)
+    if (gathered[k].scenario_id != INT32_MIN) {
+      const topay_record_t q = gathered[k];   // (gathered and all may be the same buffer: n <= k)
+      all[n++] = q;
+    }
+  for (size_t k = n; k < tot; k++) record_padding(all[k]);
+  if (n_valid) *n_valid = (int)n;
+  return TOPAY_OK;
+}
+
 topay_status topay_gather_records(topay_ctx* c, const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* all, int* n_valid) {
   if (!c || !c->comm) { set_err("topay_gather_records: no communicator (topay_comm_init)"); return TOPAY_ERR_INVALID_ARG; }
   if (n_mine < 0 || per_rank <= 0 || n_mine > per_rank || (n_mine > 0 && !mine) || !all) return TOPAY_ERR_INVALID_ARG;
@@ -2321,22 +2346,14 @@ topay_status topay_gather_records(topay_ctx* c, const topay_record_t* mine, int 
   topay_status s;
   if ((s = c->comm_send.ensure(bytes)) != TOPAY_OK || (s = c->comm_recv.ensure(bytes * c->comm_world)) != TOPAY_OK) return s;
   std::vector<topay_record_t> pad((size_t)per_rank);
-  for (int r = 0; r < per_rank; r++) {
-    if (r < n_mine) pad[r] = mine[r];
-    else { pad[r].scenario_id = INT32_MIN; pad[r].best_candidate = -1; pad[r].status = 0; pad[r].n_pieces = 0; pad[r].cost = 0.0; pad[r].duration = 0.0; }
-  }
+  (void)topay_pack_records(mine, n_mine, per_rank, pad.data());
   HIPCHK(hipMemcpyAsync(c->comm_send.p, pad.data(), bytes, hipMemcpyHostToDevice, c->comm_stream));
   const int rc = a->AllGather(c->comm_send.p, c->comm_recv.p, bytes, 0 /* ncclInt8 */, c->comm, c->comm_stream);
   if (rc != 0) return rccl_fail("ncclAllGather", rc);
   std::vector<topay_record_t> got((size_t)per_rank * c->comm_world);
   HIPCHK(hipMemcpyAsync(got.data(), c->comm_recv.p, bytes * c->comm_world, hipMemcpyDeviceToHost, c->comm_stream));
   HIPCHK(hipStreamSynchronize(c->comm_stream));
-  int n = 0;
-  for (const topay_record_t& q : got)
-    if (q.scenario_id != INT32_MIN) all[n++] = q;
-  for (size_t k = n; k < got.size(); k++) { all[k].scenario_id = INT32_MIN; all[k].best_candidate = -1; all[k].status = 0; all[k].n_pieces = 0; all[k].cost = 0.0; all[k].duration = 0.0; }
-  if (n_valid) *n_valid = n;
-  return TOPAY_OK;
+  return topay_unpack_records(got.data(), c->comm_world, per_rank, all, n_valid);
 }
 
 // Launch class of a candidate with n_pieces pieces: waves per trajectory and decision-vector elements per thread of
