@@ -377,6 +377,9 @@ def main():
         o1.close()
         w1.close()
     simd_slots = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
+    ev_ = (stats[:, 2] + stats[:, 5]).astype(np.float64) * (n_pieces > 0)
+    np_ = np.maximum(n_pieces, 1).astype(np.float64)
+    lane_util = float((ev_ * 13.0 * np_).sum() / max(1.0, (ev_ * 64.0 * np.ceil(13.0 * np_ / 64.0)).sum()))
     gate_timeouts = int(sum(o_.gate_timeouts() for o_ in opts))
     abytes = algorithmic_bytes(stats, n_pieces)
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
@@ -391,15 +394,26 @@ def main():
     # HBM-side bytes of one step from the committed PMC passes of this same command (tools/profile_round.sh; FETCH_SIZE
     # and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected live here).  Only quoted when the
     # workload is the one that was profiled.
+    # The figure is tied to the kernel sources it was measured on (source_sha written by tools/summarize_profile.py): with
+    # other sources in the tree it is not quoted (traffic null, the reason in traffic_source).
     traffic, traffic_src = None, None
     try:
         import glob
+        import hashlib
 
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_hires.json" if hires else "r*_traffic.json")))
         if cands and S == 1024 and Ccand == 8:
             tj = json.load(open(cands[-1]))
-            traffic = float(tj["traffic_bytes"])
-            traffic_src = os.path.relpath(cands[-1], ROOT)
+            h_ = hashlib.sha256()
+            csrc = os.path.join(ROOT, "topay_amd", "csrc")
+            for fn in sorted(os.listdir(csrc)):
+                h_.update(open(os.path.join(csrc, fn), "rb").read())
+            if tj.get("source_sha") == h_.hexdigest()[:16]:
+                traffic = float(tj["traffic_bytes"])
+                traffic_src = os.path.relpath(cands[-1], ROOT) + " (PMC passes of this command on these kernel sources)"
+            else:
+                traffic_src = (os.path.relpath(cands[-1], ROOT) + " was measured on other kernel sources (source_sha differs): not quoted; "
+                               "tools/profile_round.sh collects it again")
     except (OSError, ValueError, KeyError):
         pass
     out = {
@@ -431,6 +445,13 @@ def main():
             # candidates the device did not solve (more pieces than the build supports): none may hide in `value`
             "n_not_launched": n_not_launched, "success_fraction": float(ok.mean()),
             "gate_pass_fraction_of_successes": float(gate[ok].mean()) if ok.any() else 0.0,
+            # what a planner could use of `value`: candidates that converged AND pass printConstraintsSituations
+            # (planner.cpp:878-880), this rank's fraction applied to the whole-job rate
+            "accepted_fraction": float((ok & gate).mean()),
+            "accepted_trajectories_per_s": float((ok & gate).sum() / max(1, B - n_not_launched) * total_traj * args.steps / elapsed),
+            # samples evaluated per sample slot of the 64-lane passes (13 N samples in ceil(13 N / 64) passes), weighted by
+            # every candidate's evaluations: every multiple of five pieces pays a whole pass for N / 5 samples
+            "lane_utilisation_sweeps": lane_util,
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
             "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),
@@ -463,11 +484,15 @@ def main():
             "kernel_span_ms_each": [float(k) for k in kernel_ms], "steps_in_flight": depth,
             "serial_steps": serial,
             "algorithmic_bytes_per_step": abytes,
-            # work per slot: sum of the per-candidate device times of one step / SIMD slots; ms_per_step / this = how
-            # much longer a step takes than perfectly packed slots would (tail, hand-over between batches, LDS residency)
+            # wave-seconds of one step (per-candidate device times x the waves of its workgroup) over the SIMDs there are.
+            # Since round 4 the kernels fit two waves per SIMD (256 registers, LDS permitting), so the mean number of
+            # resident waves per SIMD can pass 1 (at most 2); a wave that shares its SIMD runs slower, so wave-seconds
+            # are not comparable with rounds 1-3's one-wave-per-SIMD slot-seconds.
             "slot_seconds_per_step": slot_seconds, "simd_slots": simd_slots,
             "work_ms_per_slot": slot_seconds / simd_slots * 1e3,
             "slot_utilisation": slot_seconds / simd_slots / (elapsed / args.steps),
+            "resident_waves_per_simd_mean": slot_seconds / simd_slots / (elapsed / args.steps),
+            "waves_per_simd_built_for": 2,
         },
     }
     if gate_timeouts:

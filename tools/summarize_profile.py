@@ -144,7 +144,13 @@ def main(src, dst, tag, suffix=""):
         out.append(f"- WRITE_SIZE: {w / 1e9:.1f} GB")
         out.append(f"- traffic = 2 x FETCH_SIZE + WRITE_SIZE = {(2 * f + w) / 1e9:.1f} GB per step "
                    f"(upper bound: the gather share of the reads needs no x2)")
-        json.dump({"fetch_bytes_reported": f, "write_bytes": w, "traffic_bytes": 2 * f + w},
+        # source_sha ties the figure to the kernel sources it was measured on: bench.py only quotes it for the same sources
+        import hashlib
+        h = hashlib.sha256()
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "topay_amd", "csrc")
+        for fn in sorted(os.listdir(csrc)):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+        json.dump({"fetch_bytes_reported": f, "write_bytes": w, "traffic_bytes": 2 * f + w, "source_sha": h.hexdigest()[:16]},
                   open(os.path.join(dst, f"{tag}_traffic{suffix}.json"), "w"))
     open(os.path.join(dst, f"{tag}_rocprof_summary{suffix}.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))

@@ -84,6 +84,11 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
+// A function-local device buffer: released on every way out (the early returns of the HIPCHK macro included).
+struct ScopedDevBuf : DevBuf {
+  ~ScopedDevBuf() { release(); }
+};
+
 // Launch buckets by number of pieces: upper bounds (inclusive) = one bucket per kernel template (rows per lane 1 / 2 / 3 / 4 / 6).
 // Each bucket is one launch on its own stream so that they run concurrently.  All streams have the SAME priority:
 // mixed priorities made the hardware preempt (context-save) the low-priority waves whenever high-priority work
@@ -180,6 +185,7 @@ struct topay_ctx {
   std::vector<topay_ctx*> map_owner = std::vector<topay_ctx*>(TOPAY_MAX_MAPS, nullptr);
   std::vector<topay_ctx*> map_sharers;
   std::vector<int> h_map_id;   // map slot of every candidate of the resident batch
+  std::vector<int> h_path_len; // init-path states of every candidate (launch order inside a class)
   // batch
   int B = 0, Nmax = 0, total_states = 0, Pmax = 0;
   // pieces / decision-vector elements of the candidates before b (packed per-candidate blocks, DevBatch::poff / noff)
@@ -407,6 +413,7 @@ topay_status topay_set_params(topay_ctx* c, const topay_params_t* params) {
   return TOPAY_OK;
 }
 
+static topay_status create_device_state(topay_ctx* c, int device);
 topay_status topay_create(const topay_params_t* params, int device, topay_ctx** out) {
   if (!params || !out) return TOPAY_ERR_INVALID_ARG;
   { topay_status vs = validate_params(params); if (vs != TOPAY_OK) return vs; }
@@ -421,6 +428,18 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
   c->device = device;
   c->hp = *params;
   make_dev_params(*params, c->dp);
+  // a failure below releases what has been created so far (topay_destroy copes with a partly built context)
+  const topay_status st = create_device_state(c, device);
+  if (st != TOPAY_OK) { topay_destroy(c); return st; }
+  {
+    std::lock_guard<std::mutex> lk(g_registry_mutex);
+    g_contexts.push_back(c);
+  }
+  *out = c;
+  return TOPAY_OK;
+}
+
+static topay_status create_device_state(topay_ctx* c, int device) {
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
@@ -466,13 +485,8 @@ topay_status topay_create(const topay_params_t* params, int device, topay_ctx** 
     c->h_cancel[0] = 0;
     { const char* ge = exp_env("TOPAY_GATE_IN_SOLVE"); c->gate_in_solve = !(ge && ge[0] == '0'); }
   }
-  if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) { delete c; return TOPAY_ERR_NO_DEVICE; }
+  if (c->dmaps.ensure(sizeof(DevMap) * TOPAY_MAX_MAPS) != TOPAY_OK) return TOPAY_ERR_NO_DEVICE;
   memset(c->hmaps.data(), 0, sizeof(DevMap) * TOPAY_MAX_MAPS);
-  {
-    std::lock_guard<std::mutex> lk(g_registry_mutex);
-    g_contexts.push_back(c);
-  }
-  *out = c;
   return TOPAY_OK;
 }
 
@@ -998,6 +1012,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
     if (c->hN[b] == 0) continue;
     c->cls[bucket_of(c->hN[b])].push_back(b);
   }
+  c->h_path_len.assign(path_len, path_len + batch);
   {
     std::vector<int> ord;
     for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) ord.insert(ord.end(), c->cls[k].begin(), c->cls[k].end());
@@ -1129,10 +1144,11 @@ static hipError_t set_kernel_attributes(int device) {
     (void)device;
     hipError_t e = hipSuccess;
     const ClassDef* ct = class_table();
+    // The whole LDS of a compute unit for every kernel: the request of a launch is not monotone in the longest candidate
+    // (the four-wave class switches to the compact layout where the full one stops fitting, so N = 95 asks for more than
+    // N = 128), and an attribute below a launch's request is an error on a runtime that enforces it.
+    const int lds = kLdsDoublesPerCU * 8;
     for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
-      int lds = 0;   // classes that share a kernel: the largest request
-      for (int k2 = 0; k2 < TOPAY_NBUCKET; k2++)
-        if (ct[k2].solve == ct[k].solve) lds = std::max(lds, (int)class_lds_bytes(ct[k2], ct[k2].max_n));
       e = hipFuncSetAttribute((const void*)ct[k].solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ct[k].eval, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
@@ -1299,7 +1315,13 @@ topay_status topay_optimize_async(topay_ctx* c) {
   HIPCHK(hipMemsetAsync(c->success.p, 0, (size_t)c->B * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->cost.p, 0xFF, (size_t)c->B * 8, c->stream));
   topay_status s = launch_classes<false>(c, c->persistent);
-  if (s != TOPAY_OK) return s;
+  if (s != TOPAY_OK) {
+    // some class launches may already be running on the batch's buffers: nothing may touch them before they have ended
+    for (int k = 0; k < topay_ctx::NBUCKET; k++)
+      if (c->bstream[k]) (void)hipStreamSynchronize(c->bstream[k]);
+    (void)hipStreamSynchronize(c->stream);
+    return s;
+  }
   HIPCHK(hipEventRecord(c->ev1, c->stream));
   c->pending = true;
   return TOPAY_OK;
@@ -1357,44 +1379,67 @@ topay_status topay_synchronize(topay_ctx* c) {
 // With a positive cancel budget the candidates of a call that are still running `budget` piece-evaluations after the
 // call's first success that passes the gate are interrupted (threads.interrupt_all() 100 ms after future_succ; the unit
 // is alm_work_budget's: 24 000 = 1 s, so 100 ms = 2400).  Call after topay_set_init_traj; 0 / NULL switches it off.
+// Launch order of the resident batch: inside every class longest first (the tail of a batch), or -- with the planner's
+// cancellation -- shortest first (see topay_set_groups).
+static topay_status upload_order(topay_ctx* c, bool shortest_first) {
+  std::vector<int> ord;
+  for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
+    std::vector<int>& v = c->cls[k];
+    if (shortest_first) std::stable_sort(v.begin(), v.end(), [&](int a, int b2) { return c->hN[a] < c->hN[b2]; });
+    else std::stable_sort(v.begin(), v.end(), [&](int a, int b2) {
+      return c->hN[a] != c->hN[b2] ? c->hN[a] > c->hN[b2] : (c->h_path_len[a] != c->h_path_len[b2] ? c->h_path_len[a] > c->h_path_len[b2] : a < b2);
+    });
+    ord.insert(ord.end(), v.begin(), v.end());
+  }
+  ord.resize(c->B, 0);
+  HIPCHK(memcpy_sync(c, c->order.p, ord.data(), (size_t)c->B * 4, hipMemcpyHostToDevice));
+  return TOPAY_OK;
+}
+
 topay_status topay_set_groups(topay_ctx* c, const int* group_id, int cancel_budget) {
-  if (!c || !c->have_traj || cancel_budget < 0) return TOPAY_ERR_NO_TRAJ;
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (cancel_budget < 0) return TOPAY_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->device));
   if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }
+  const bool had_groups = c->n_groups > 0;
   c->h_group.clear();
   c->n_groups = 0;
   c->cancel_budget = cancel_budget;
   c->db.group_id = nullptr; c->db.group_tau = nullptr;
-  if (!group_id || cancel_budget == 0) return TOPAY_OK;
-  if (!c->gate_in_solve) { set_err("cancellation needs the in-solve feasibility gate (TOPAY_GATE_IN_SOLVE=0 is set)"); return TOPAY_ERR_UNSUPPORTED; }
-  int ng = 0;
-  for (int b = 0; b < c->B; b++) {
-    if (group_id[b] < -1) return TOPAY_ERR_INVALID_ARG;
-    ng = std::max(ng, group_id[b] + 1);
+  if (!group_id || cancel_budget == 0) {
+    if (had_groups) return upload_order(c, false);   // back to longest first
+    return TOPAY_OK;
   }
-  c->h_group.assign(group_id, group_id + c->B);
-  c->n_groups = ng;
+  if (!c->gate_in_solve) { set_err("cancellation needs the in-solve feasibility gate (TOPAY_GATE_IN_SOLVE=0 is set)"); return TOPAY_ERR_UNSUPPORTED; }
+  // the caller's ids (any integers >= 0, e.g. global scenario numbers of a sharded sweep; -1 = no planning call) become
+  // dense indices: the device holds one clock per planning call that is present, not one per possible id
+  std::vector<int> dense(c->B, -1);
+  {
+    std::vector<int> ids;
+    for (int b = 0; b < c->B; b++) {
+      if (group_id[b] < -1) return TOPAY_ERR_INVALID_ARG;
+      if (group_id[b] >= 0) ids.push_back(group_id[b]);
+    }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    for (int b = 0; b < c->B; b++)
+      if (group_id[b] >= 0) dense[b] = (int)(std::lower_bound(ids.begin(), ids.end(), group_id[b]) - ids.begin());
+    c->n_groups = (int)ids.size();
+  }
+  const int ng = c->n_groups;
+  c->h_group = dense;
+  if (ng == 0) { c->cancel_budget = cancel_budget; return TOPAY_OK; }
   topay_status s;
   if ((s = c->group_id.ensure((size_t)c->B * 4)) != TOPAY_OK) return s;
   if ((s = c->group_tau.ensure((size_t)std::max(1, ng) * 4)) != TOPAY_OK) return s;
-  HIPCHK(memcpy_sync(c, c->group_id.p, group_id, (size_t)c->B * 4, hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(c, c->group_id.p, dense.data(), (size_t)c->B * 4, hipMemcpyHostToDevice));
   c->db.group_id = c->group_id.as<int>();
   c->db.group_tau = c->group_tau.as<int>();
   // Launch order with cancellation: shortest candidates first inside every class.  Without it the longest go first (they
   // are the tail of the batch); with it they are the ones the rule interrupts, and they can only be stopped early if the
   // short candidates of their planning call -- the ones that succeed first on the work clock -- have already run.  The
   // outcome does not depend on the order (the rule is applied to the candidates' own clocks), only the time saved does.
-  {
-    std::vector<int> ord;
-    for (int k = topay_ctx::NBUCKET - 1; k >= 0; k--) {
-      std::vector<int>& v = c->cls[k];
-      std::stable_sort(v.begin(), v.end(), [&](int a, int b2) { return c->hN[a] < c->hN[b2]; });
-      ord.insert(ord.end(), v.begin(), v.end());
-    }
-    ord.resize(c->B, 0);
-    HIPCHK(memcpy_sync(c, c->order.p, ord.data(), (size_t)c->B * 4, hipMemcpyHostToDevice));
-  }
-  return TOPAY_OK;
+  return upload_order(c, true);
 }
 
 // threads.interrupt_all() for the solve in flight (planner.cpp:952): every candidate stops at its next interruption
@@ -1695,7 +1740,7 @@ topay_status topay_plan2d_jps(topay_ctx* c, int n, const int* map_ids, const dou
   // chunks of at most 2 GB of it
   const size_t per = (size_t)ncell * 21;
   const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)2 << 30) / std::max<size_t>(per, 1)));
-  DevBuf ws, io;
+  ScopedDevBuf ws, io;
   topay_status s;
   if ((s = ws.ensure((size_t)chunk * per + 64)) != TOPAY_OK) return s;
   const size_t io_d = (size_t)n * 4 + (size_t)n * cap_points * 2, io_i = (size_t)n * 4;
@@ -1838,7 +1883,7 @@ topay_status topay_reeds_shepp(topay_ctx* c, int n, const double* from, const do
   if (!c || n < 0 || !(rho > 0.0) || (n > 0 && (!from || !to))) return TOPAY_ERR_INVALID_ARG;
   if (n == 0) return TOPAY_OK;
   HIPCHK(hipSetDevice(c->device));
-  DevBuf d;
+  ScopedDevBuf d;
   topay_status s;
   if ((s = d.ensure((size_t)n * (3 + 3 + 1 + 1 + 5 + 3 + 1) * 8)) != TOPAY_OK) return s;
   double* d_from = d.as<double>();
@@ -2029,7 +2074,7 @@ static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, co
                    alm_rho ? alm_rho[0] : c->hp.alm_init_rho[0], alm_rho ? alm_rho[1] : c->hp.alm_init_rho[1]};
   HIPCHK(memcpy_sync(c, c->alm.as<double>() + (size_t)i * 4, alm, 32, hipMemcpyHostToDevice));
   // single-block launch through a one-entry order array placed at the end of the order buffer
-  DevBuf tmp;
+  ScopedDevBuf tmp;
   topay_status s = tmp.ensure(4);
   if (s != TOPAY_OK) return s;
   HIPCHK(memcpy_sync(c, tmp.p, &i, 4, hipMemcpyHostToDevice));
@@ -2040,7 +2085,7 @@ static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, co
   const size_t lds = class_lds_bytes(cd, N);
   if ((s = push_params(c)) != TOPAY_OK) return s;
   HIPCHK(set_kernel_attributes(c->device));
-  if (force_nw > 0) HIPCHK(hipFuncSetAttribute((const void*)cd.eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)class_lds_bytes(cd, cd.max_n)));
+  if (force_nw > 0) HIPCHK(hipFuncSetAttribute((const void*)cd.eval, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoublesPerCU * 8));
   hipLaunchKernelGGL(cd.eval, dim3(1), dim3(64 * cd.nw), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N, class_compact(cd, N));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2278,7 +2323,9 @@ topay_status topay_comm_destroy(topay_ctx* c) {
 // order of first appearance, best_candidate relative to the scenario's first candidate, -1 / status 0 without a winner.
 topay_status topay_scenario_records(topay_ctx* c, const int* scenario_of, int cap_records, topay_record_t* records, int* n_records,
                                     int* winner_index /* cap_records, may be null: batch index of each winner or -1 */) {
-  if (!c || !c->have_traj || !c->solved) return TOPAY_ERR_NO_TRAJ;
+  if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
+  if (c->pending) { topay_status ws = topay_synchronize(c); if (ws != TOPAY_OK) return ws; }   // (waits like the other getters)
+  if (!c->solved) return TOPAY_ERR_NO_TRAJ;
   if (!scenario_of || !records || !n_records || cap_records < 0) return TOPAY_ERR_INVALID_ARG;
   const int B = c->B;
   std::vector<int> ok(B), feas(B);
