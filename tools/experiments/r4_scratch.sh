@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/r4i; mkdir -p $O
+echo "== hash new"; timeout 300 python3 tools/gpu_hashrun.py 2>&1 | tail -1
+A="--steps 12 --warmup 3 --no-cpu-baseline --no-planner --no-config1"
+run() { tag=$1; shift; timeout -s KILL 400 "$@" > $O/b_$tag.json 2> $O/b_$tag.err; python3 tools/pj.py "$tag" < $O/b_$tag.json || tail -3 $O/b_$tag.err; }
+run prev_1 env TOPAY_LIB=$PWD/tools/libs/libtopay_prev.so python3 bench.py $A
+run new_1 python3 bench.py $A
+run prev_2 env TOPAY_LIB=$PWD/tools/libs/libtopay_prev.so python3 bench.py $A
+run new_2 python3 bench.py $A
+run prev_3 env TOPAY_LIB=$PWD/tools/libs/libtopay_prev.so python3 bench.py $A
+run new_3 python3 bench.py $A

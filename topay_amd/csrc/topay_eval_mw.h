@@ -135,10 +135,33 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   glb_cdp Arc = c_x + 2 * N - 1;
   glb_cdp Vq = c_x + 3 * N - 1;
 
+  // Everything this function reads from HBM is requested first -- the decision vector (written by the solver a moment
+  // ago) and the boundary conditions -- so that the zero fills below run under the loads' latency instead of ahead of it
+  // (the wave-level fences of the LDS hand-offs keep the compiler from moving loads up by itself).
+  const double tau_v = tid < N ? Tau[tid] : 0.0;
+  constexpr int NI = 9;   // inner-point values per thread: 9 (N - 1) <= 9 NT
+  double inner_v[NI];
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int t = tid + NT * u;
+    inner_v[u] = 0.0;
+    if (t < 9 * (N - 1)) {
+      const int i = t / 9, d = t - 9 * i;
+      const int dq = d >= 2 ? d - 2 : 0;   // (clamped: the compiler may issue the loads of all three branches)
+      inner_v[u] = d == 0 ? Theta[i] : (d == 1 ? Arc[i] : Vq[i * 7 + dq]);
+    }
+  }
+  double bc_v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (tid < 9) {
+    const int d = tid;
+    bc_v[0] = c_hd[0 * 9 + d]; bc_v[1] = c_hd[1 * 9 + d]; bc_v[2] = c_hd[2 * 9 + d];
+    bc_v[3] = (d == 1) ? Arc[N - 1] : c_tl[0 * 9 + d];   // minco_end_state(1,0) = Arc[N-1]
+    bc_v[4] = c_tl[1 * 9 + d]; bc_v[5] = c_tl[2 * 9 + d];
+  }
   for (int t = tid; t < 13 * rows; t += NT) band[t] = 0.0;
   for (int t = tid; t < 9 * rows; t += NT) cL[t] = 0.0;
   if (tid < N) {
-    double T1 = expC2(Tau[tid]);
+    double T1 = expC2(tau_v);  // calTfromTau, moma_traj_opt.h:778-786
     double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
     c_Tp[0 * N + tid] = T1; c_Tp[1 * N + tid] = T2; c_Tp[2 * N + tid] = T3;
     c_Tp[3 * N + tid] = T4; c_Tp[4 * N + tid] = T5;
@@ -174,21 +197,21 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   }
   if (tid < 9) {
     const int d = tid;
-    cL[d * rows + 0] = c_hd[0 * 9 + d];
-    cL[d * rows + 1] = c_hd[1 * 9 + d];
-    cL[d * rows + 2] = c_hd[2 * 9 + d];
-    cL[d * rows + rows - 3] = (d == 1) ? Arc[N - 1] : c_tl[0 * 9 + d];
-    cL[d * rows + rows - 2] = c_tl[1 * 9 + d];
-    cL[d * rows + rows - 1] = c_tl[2 * 9 + d];
+    cL[d * rows + 0] = bc_v[0];
+    cL[d * rows + 1] = bc_v[1];
+    cL[d * rows + 2] = bc_v[2];
+    cL[d * rows + rows - 3] = bc_v[3];
+    cL[d * rows + rows - 2] = bc_v[4];
+    cL[d * rows + rows - 1] = bc_v[5];
   }
-  for (int t = tid; t < 9 * (N - 1); t += NT) {
-    const int i = t / 9, d = t - 9 * i;
-    const int dq = d >= 2 ? d - 2 : 0;
-    double v;
-    if (d == 0) v = Theta[i];
-    else if (d == 1) v = Arc[i];
-    else v = sigmoidC2(Vq[i * 7 + dq], P.joint_pos_limit_max[dq]);
-    cL[d * rows + 6 * i + 5] = v;
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int t = tid + NT * u;
+    if (t < 9 * (N - 1)) {
+      const int i = t / 9, d = t - 9 * i;
+      const int dq = d >= 2 ? d - 2 : 0;
+      cL[d * rows + 6 * i + 5] = d >= 2 ? sigmoidC2(inner_v[u], P.joint_pos_limit_max[dq]) : inner_v[u];
+    }
   }
   wg_barrier<NW>();
   // LU without pivoting on wave 0 (banded_system.hpp:66-91); the other waves wait at the barrier below
@@ -226,32 +249,38 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
 template <int STAGE, int RMAX, int NW, int OCC = 1>
 __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
   constexpr int NT = 64 * NW;
-  const lds_dp c_Tp = C.Tp;
-  const lds_dp c_X = C.X;
-  const double c_ex = C.ex;
-  const double c_ey = C.ey;
-  const glb_dp c_g = C.g;
-  const lds_dp c_gdT = C.gdT;
-  const glb_cdp c_init_xy = C.init_xy;
-  const double c_lam0 = C.lam0;
-  const double c_lam1 = C.lam1;
-  const glb_dp c_lu = C.lu;
-  const lds_dp c_pcs = C.pcs;
-  const lds_dp c_pw = C.pw;
-  const double c_rho0 = C.rho0;
-  const double c_rho1 = C.rho1;
-  const double c_sx = C.sx;
-  const double c_sy = C.sy;
-  const glb_cdp c_x = C.x;
-  const lds_dp c_red = C.red;
-  const lds_dp c_adj = C.adj;
-  const glb_dp c_coefg = C.coefg;
+  // (wave-uniform context fields into scalar registers: what stays in vector registers is saved and restored around every
+  // call of the manipulator block)
+  const lds_dp c_Tp = uniform_ptr(C.Tp);
+  const lds_dp c_X = uniform_ptr(C.X);
+  const double c_ex = uniform_f64(C.ex);
+  const double c_ey = uniform_f64(C.ey);
+  const glb_dp c_g = uniform_ptr(C.g);
+  const lds_dp c_gdT = uniform_ptr(C.gdT);
+  const glb_cdp c_init_xy = uniform_ptr(C.init_xy);
+  const double c_lam0 = uniform_f64(C.lam0);
+  const double c_lam1 = uniform_f64(C.lam1);
+  const glb_dp c_lu = uniform_ptr(C.lu);
+  const lds_dp c_pcs = uniform_ptr(C.pcs);
+  const lds_dp c_pw = uniform_ptr(C.pw);
+  const double c_rho0 = uniform_f64(C.rho0);
+  const double c_rho1 = uniform_f64(C.rho1);
+  const double c_sx = uniform_f64(C.sx);
+  const double c_sy = uniform_f64(C.sy);
+  const glb_cdp c_x = uniform_ptr(C.x);
+  const lds_dp c_red = uniform_ptr(C.red);
+  const lds_dp c_adj = uniform_ptr(C.adj);
+  const glb_dp c_coefg = uniform_ptr(C.coefg);
   const bool compact = __builtin_amdgcn_readfirstlane(C.compact) != 0;
 
   const DevParams& P = g_P;
   const int lane = C.lane, tid = C.tid, wave = __builtin_amdgcn_readfirstlane(C.wave);
   const int N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
-  lds_cdp cL = C.cL;
+  lds_cdp cL = uniform_ptr(C.cL);
+  const glb_dp c_sbuf = uniform_ptr(C.sbuf);
+  const int c_sbs = __builtin_amdgcn_readfirstlane(C.sb_stride);
+  const double g_skip_thr = uniform_f64(gate.skip_thr);
+  const bool g_early_ok = __builtin_amdgcn_readfirstlane(gate.early_ok ? 1 : 0) != 0;
   int rp = 0;                                  // phase of the workgroup-reduction scratch
   const int npl = __builtin_amdgcn_readfirstlane(C.npass_lds);
   const lds_dp ptot = c_red + 8;               // [npass][2] pass totals of the XY prefix / chain suffix
@@ -299,9 +328,9 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const double time_cost = wT * wg_sum<NW>(c_red, rp, wave, tid < N ? c_Tp[tid] : 0.0);
   bool skip_body = false;
   double f_skip = 0.0;
-  if (STAGE == 2 && gate.early_ok) {
+  if (STAGE == 2 && g_early_ok) {
     const double partial = jerk_cost + time_cost;
-    if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
+    if (partial > g_skip_thr && partial <= 1.79769313486231570e308) {
       skip_body = true;
       f_skip = partial;
     }
@@ -383,8 +412,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       if (act && !skip_body) {
         gxy[2 * e] = gpx;
         gxy[2 * e + 1] = gpy;
-        glb_dp sb = C.sbuf + e;
-        const int ss = C.sb_stride;
+        glb_dp sb = c_sbuf + e;
+        const int ss = c_sbs;
 #pragma unroll
         for (int v = 0; v < 5; v++) sb[v * ss] = gB[v];
         sb[5 * ss] = gdTs;
@@ -407,9 +436,9 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       const int p2 = k * NW + q;
       if (p2 < npass) {
         cost_pen += NW > 1 ? cs[q * 64 + lane] : cst_out;
-        if (STAGE == 2 && gate.early_ok && !skip_body && p2 + 1 < npass) {
+        if (STAGE == 2 && g_early_ok && !skip_body && p2 + 1 < npass) {
           const double partial = jerk_cost + wave_sum(cost_pen) + time_cost;
-          if (partial > gate.skip_thr && partial <= 1.79769313486231570e308) {
+          if (partial > g_skip_thr && partial <= 1.79769313486231570e308) {
             skip_body = true;
             f_skip = partial;
           }
@@ -505,8 +534,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       bool jva = false;
       double rawq[7];
       {
-        glb_cdp sb = C.sbuf + (act ? e : NE - 1);
-        const int ss = C.sb_stride;
+        glb_cdp sb = c_sbuf + (act ? e : NE - 1);
+        const int ss = c_sbs;
         double raw[14];
 #pragma unroll
         for (int v = 0; v < ((STAGE == 2) ? 14 : 6); v++) raw[v] = sb[v * ss];
@@ -655,8 +684,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     const double step = c_Tp[i] / TOPAY_K, half = step / 2.0;
     bool jva = false;
     if (pass < npass) {
-      glb_cdp sb = C.sbuf + (act ? e : NE - 1);
-      const int ss = C.sb_stride;
+      glb_cdp sb = c_sbuf + (act ? e : NE - 1);
+      const int ss = c_sbs;
       double raw[14];
 #pragma unroll
       for (int v = 0; v < ((STAGE == 2) ? 14 : 6); v++) raw[v] = sb[v * ss];
