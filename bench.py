@@ -439,7 +439,7 @@ def main():
                          + ("; init paths from the device's MCRRTs::plan (--front-end)" if front_end else "")),
             "front_end": front_end,
             "scenarios_per_gpu": S, "candidates": Ccand, "trajectories_per_gpu": B,
-            "parallelism": f"scenario-sharded x{world}, one workgroup (1, 2 or 4 wavefronts) per trajectory, {depth} batches in flight per GPU",
+            "parallelism": f"scenario-sharded x{world}, one workgroup (1 or 4 wavefronts) per trajectory, {depth} batches in flight per GPU",
             "mean_pieces": float(n_pieces.mean()), "max_pieces": int(n_pieces.max()),
             "pieces_over_32": int((n_pieces > 32).sum()),
             # candidates the device did not solve (more pieces than the build supports): none may hide in `value`
@@ -475,7 +475,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3 + k_solve2w2/3w2/3w4 (persistent solve: one workgroup of 1, 2 or 4 waves per trajectory takes candidates from its class's queue; the "
+            "kernel": "k_solve1/2/3 + k_solve2w4/3w4 (persistent solve: one workgroup of 1 or 4 waves per trajectory takes candidates from its class's queue; the "
                       "up to six class launches of a batch run concurrently)",
             "kernel_ms": kms,
             "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else

@@ -122,18 +122,20 @@ static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
         {10, 1, 1, k_solve1, k_eval1, 2}, {15, 2, 1, k_solve2, k_eval2, 2}, {21, 2, 1, k_solve2, k_eval2, 2}, {32, 3, 1, k_solve3, k_eval3, 2},
-        {42, 2, 2, k_solve2w2, k_eval2w2, 2}, {64, 3, 2, k_solve3w2, k_eval3w2, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2}};
-    // Two waves per trajectory for N = 33..64: measured on one box with three batches in flight (tools/experiments/r3_mw_ab.sh),
-    // one / two / four waves for both classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 /
-    // 1.03 s.  Four waves halve a long candidate's solve but occupy four SIMD slots for it (the serial parts -- LU,
-    // substitutions -- leave three of them idle), two waves fill the SIMD the candidate's LDS would idle anyway.
+        {42, 2, 4, k_solve2w4, k_eval2w4, 2}, {64, 2, 4, k_solve2w4, k_eval2w4, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2}};
+    // Four waves per trajectory for N = 33..64 since round 4.  Round 3 (one wave per SIMD), one / two / four waves for both
+    // classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 / 1.03 s -- four waves halve a long
+    // candidate's solve but held four SIMDs for it.  With two waves per SIMD a wave holds half a SIMD, the common classes
+    // got faster and the long candidates set the length of a batch again (their launch was the longest of a serial step,
+    // 1.06-1.21 s): two / four waves for N = 43..64 now give 11.5-11.6k / 11.8-11.9k and serial steps of 1.07 / 0.95 s, four
+    // for N = 33..42 as well 0.94 s (tools/experiments/r4_mw.sh).
 #ifdef TOPAY_EXPERIMENTS
     auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    const int w4 = env_nw("TOPAY_MW_C4", 2), w5 = env_nw("TOPAY_MW_C5", 2);
+    const int w4 = env_nw("TOPAY_MW_C4", 4), w5 = env_nw("TOPAY_MW_C5", 4);
     if (w4 == 1) t[4] = {42, 4, 1, k_solve4, k_eval4, 2};
-    else if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 2};
+    else if (w4 == 2) t[4] = {42, 2, 2, k_solve2w2, k_eval2w2, 2};
     if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6, 2};
-    else if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 2};
+    else if (w5 == 2) t[5] = {64, 3, 2, k_solve3w2, k_eval3w2, 2};
 #endif
     return t;
   }();

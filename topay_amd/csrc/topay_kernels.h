@@ -308,8 +308,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, 2)
-TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, 2)
+TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
 TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, 2)
 TOPAY_EVAL_KERNEL(k_eval1, 1, 1, 2)
 TOPAY_EVAL_KERNEL(k_eval2, 2, 1, 2)
@@ -327,7 +326,8 @@ TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, 2)
 // for N <= 64
 TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
+TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, 2)
+TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, 2)
 #endif
 #endif  // TOPAY_NO_KERNEL_TABLE
 
