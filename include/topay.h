@@ -445,6 +445,12 @@ topay_status topay_set_groups(topay_ctx* ctx, const int* group_id /* batch */, i
  * point.  Returns at once (callable from another thread than the one in topay_synchronize). */
 topay_status topay_cancel(topay_ctx* ctx);
 topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */);
+/* The wall-clock knob of a planning call (max_replan_time, agent_benchmark_tables.yaml:6; the 1.0 s cap of the ALM loop,
+ * moma_traj_opt.cpp:403-407, is of the same kind): topay_optimize_async, then topay_cancel if the batch has not finished
+ * within budget_ms of wall time, then topay_synchronize.  Candidates that finished in time keep their results; the rest
+ * return TOPAY_INTERRUPTED.  *timed_out (may be NULL) tells whether the cancel was needed.  Unlike the deterministic
+ * budgets (alm_max_outer, alm_work_budget, topay_set_groups) the outcome depends on the machine and its load. */
+topay_status topay_optimize_within(topay_ctx* ctx, double budget_ms, int* timed_out);
 
 /* ---- multi-GPU: scenarios shard over the GPUs of a node (one process per GPU, nothing of the solve is shared); the one
  * exchange is the all-gather of a 32-byte record per scenario over RCCL (the reference's selection of

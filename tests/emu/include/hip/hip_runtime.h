@@ -320,6 +320,7 @@ enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
+enum { hipErrorNotReady = 600 };
 inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
 struct hipDeviceProp_t { int multiProcessorCount = 2; };   // two 'CUs': the persistent launches of the tests really loop
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return 0; }

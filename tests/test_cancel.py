@@ -164,3 +164,36 @@ def test_cancel_everything_in_flight():
     ok2 = opt.optimize()
     assert (ok2 == ok_full).all() and (opt.stats() == st_full).all() and not opt.interrupted().any()
     tb.close()
+
+
+@pytest.mark.gpu
+def test_wall_clock_budget_interrupts_what_has_not_finished():
+    """topay_optimize_within: the wall-clock knob of a planning call (max_replan_time; the reference's 1.0 s cap of the ALM
+    loop is of the same kind).  A budget far below the batch's solve time interrupts most candidates -- they return
+    TOPAY_INTERRUPTED and no success -- and whoever finished in time keeps the result of the unbudgeted solve bit for bit; a
+    generous budget changes nothing."""
+    tb = wl.TablesBatch(64, 8, base_seed=42, nthreads=8)
+    gpu = api.MomaTrajOptBatch(device=0)
+    worlds = [tb.world(s_) for s_ in tb.scenarios]
+    w0 = worlds[0]
+    gpu.build_esdf_batch(w0.origin, w0.res, w0.dims, w0.min_b, w0.max_b, np.stack([w.occ2d for w in worlds]), np.stack([w.occ3d for w in worlds]))
+    slot = {s_: k for k, s_ in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s_] for s_ in tb.scen], dtype=np.int32)
+    ok_full = gpu.optimizeTraj(tb.lens, tb.paths, map_ids=map_ids)
+    cost_full = gpu.traj_cost.copy()
+    ms_full = gpu.last_kernel_ms()[0]
+    gpu.reset()
+    ok_gen, timed_out = gpu.optimize_within(60000.0)
+    assert not timed_out and (ok_gen == ok_full).all() and np.array_equal(np.nan_to_num(gpu.traj_cost), np.nan_to_num(cost_full))
+    assert not gpu.interrupted().any()
+    gpu.reset()
+    ok_short, timed_out = gpu.optimize_within(max(1.0, 0.15 * ms_full))
+    intr = gpu.interrupted().astype(bool)
+    print(f"full solve {ms_full:.0f} ms; budget {0.15 * ms_full:.0f} ms: {int(intr.sum())} of {len(intr)} interrupted, {int(ok_short.sum())} succeeded in time")
+    assert timed_out and intr.sum() > 0.3 * len(intr)
+    assert not (ok_short & intr).any()
+    done = ok_short & ~intr
+    assert (ok_full[done]).all() and np.array_equal(gpu.traj_cost[done], cost_full[done])
+    st = gpu.stats()
+    assert (st[intr, 3] == -2000).all()
+    tb.close()

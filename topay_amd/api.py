@@ -371,6 +371,13 @@ class MomaTrajOptBatch:
         self.traj_cost = cost
         return succ.astype(bool)
 
+    def optimize_within(self, budget_ms):
+        """optimize with a wall-clock budget (topay_optimize_within): (success flags, timed_out)."""
+        to = C.c_int(0)
+        self.L.topay_optimize_within.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
+        _chk(self.L, self.L.topay_optimize_within(self.h, float(budget_ms), C.byref(to)))
+        return self.finish(), bool(to.value)
+
     def optimize_async(self):
         """Issue the solve without waiting (several contexts may be in flight on one GPU); pair with finish()."""
         _chk(self.L, self.L.topay_optimize_async(self.h))

@@ -1467,6 +1467,23 @@ topay_status topay_optimize(topay_ctx* c) {
   return topay_synchronize(c);
 }
 
+topay_status topay_optimize_within(topay_ctx* c, double budget_ms, int* timed_out) {
+  if (timed_out) *timed_out = 0;
+  if (!(budget_ms > 0.0)) return TOPAY_ERR_INVALID_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  topay_status s = topay_optimize_async(c);
+  if (s != TOPAY_OK) return s;
+  while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= budget_ms) {
+      (void)topay_cancel(c);
+      if (timed_out) *timed_out = 1;
+      break;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  return topay_synchronize(c);
+}
+
 topay_status topay_get_nmax(topay_ctx* c, int* nmax, int* Nmax) {
   if (!c || !c->have_traj) return TOPAY_ERR_NO_TRAJ;
   if (nmax) *nmax = 10 * c->Nmax - 8;
