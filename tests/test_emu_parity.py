@@ -397,3 +397,28 @@ def test_converged_solve_equals_oracle_solver_in_device_order(cuboids_small):
     assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
             so["alm_outer"], so["sum_bound"]] == list(st)
     assert (o.get_x() == x).all() and o.traj_cost() == cost and (o.alm_state() == alm).all()
+
+
+def test_self_colliding_arm_poses_match_oracle(emu, cuboids_small):
+    """The sphere-pair path of the manipulator block (moma_traj_opt.cpp:1566-1611).  Since round 4 the pair forces of a
+    self-colliding sample do not live in registers beside the sphere centres: the lanes that have any accumulate them in
+    an HBM block and every sphere's own terms start from there.  Strongly perturbed joints fold the arm onto itself in
+    most samples (the self-collision term dominates the cost); cost and gradient against the oracle."""
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    rng = np.random.default_rng(11)
+    hit = 0
+    for b in range(min(4, len(cs["lens"]))):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        N = o.N
+        for trial in range(2):
+            x = o.get_x().copy()
+            x[3 * N - 1:] += 4.0 * rng.standard_normal(n - 3 * N + 1)
+            o.set_alm([0.1, -0.2], [1e4, 2e4])
+            f, g = o.eval(2, x)
+            t = o.debug_terms()
+            hit += t["self_colli"] > 1e3
+            fe, ge, _ = emu.eval(2, b, x, [0.1, -0.2], [1e4, 2e4])
+            assert abs(f - fe) <= 1e-12 * abs(f)
+            assert np.abs(g - ge).max() <= 1e-11 * np.abs(g).max()
+    assert hit >= 6

@@ -85,6 +85,31 @@ def test_eval_matches_oracle_and_emulator(gpu, emu, cuboids_small, stage):
             assert fg == fe and (gg == ge).all() and (eg == ee).all()  # bit-identical to the CPU execution
 
 
+def test_self_colliding_arm_poses_on_gpu(gpu, emu, cuboids_small):
+    """The sphere-pair path of the manipulator block on the device (pair forces through the HBM block, round 4): strongly
+    perturbed joints fold the arm onto itself in most samples; against the oracle at the parity tolerance and against the
+    lane emulator bit for bit."""
+    cs = cuboids_small
+    o = orc.Oracle(cs["map"])
+    rng = np.random.default_rng(11)
+    hit = 0
+    for b in range(min(4, len(cs["lens"]))):
+        n = o.set_init_traj(cs["paths"][cs["offs"][b]:cs["offs"][b + 1]])
+        N = o.N
+        for trial in range(2):
+            x = o.get_x().copy()
+            x[3 * N - 1:] += 4.0 * rng.standard_normal(n - 3 * N + 1)
+            o.set_alm([0.1, -0.2], [1e4, 2e4])
+            f, g = o.eval(2, x)
+            hit += o.debug_terms()["self_colli"] > 1e3
+            fg, gg, eg = gpu.eval(2, b, x, [0.1, -0.2], [1e4, 2e4])
+            fe, ge, ee = emu.eval(2, b, x, [0.1, -0.2], [1e4, 2e4])
+            assert abs(f - fg) <= 1e-11 * abs(f)
+            assert np.abs(g - gg).max() <= 1e-10 * np.abs(g).max()
+            assert fg == fe and (gg == ge).all() and (eg == ee).all()
+    assert hit >= 6
+
+
 def test_cost_terms_match_the_oracle_breakdown(gpu, cuboids_small):
     """Per-term cost breakdown (DebugManager, moma_traj_opt.h:566-611) on the device through topay_set_params +
     topay_eval against the oracle's accumulators, at a point where the rare terms are active."""
