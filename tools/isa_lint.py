@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ISA lint for one code-generation defect of the gfx950 compiler of this image (ROCm 7.2 clang) that this kernel family has
-hit twice, on hardware only:
+hit twice in rounds 2-3 on hardware only and twice more in round 4 at build time (docs/EXPERIMENTS.md, "The hardware-only failures"):
 
     s_cbranch_execz .LBB9_156          ; no lane takes the `if`: jump to the join block with EXEC = 0
     ...

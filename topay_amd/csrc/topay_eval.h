@@ -101,7 +101,7 @@ __device__ __forceinline__ double dpp_f64_rows(double v) {
 // 64-lane sum: a butterfly inside every row of 16 (every lane of row k then holds r_k), then across the rows:
 // (r0 + r1) + (r2 + r3), in lane 63.  The sum is 20 instructions of VALU issue -- f64 has no DPP operand form, every
 // level is two 32-bit DPP moves and an add -- and that, not the latency of the chain, is what a reduction costs
-// (DESIGN.md section 9); the cross-row levels replace four lane reads and three adds of rounds 1-2, same bits (the
+// (docs/EXPERIMENTS.md); the cross-row levels replace four lane reads and three adds of rounds 1-2, same bits (the
 // operands of every addition are the same, in the other order).
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]   : lane ^ 1
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
 #endif
     // The call sits in a block of its own, entered by a SCALAR branch the compiler cannot fold: the register allocator
     // parks what is live across the call at the top of the call's block, and when that block is the join of a divergent
-    // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (DESIGN.md section 9;
+    // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (docs/EXPERIMENTS.md, "The hardware-only failures";
     // tools/isa_lint.py found it again in round 4 when the callee's smaller register need changed the caller's allocation).
     if (topay_opaque_true()) mo_ = manipulator_block<OCC>(mp, minA_, minB_, stash_);
 #ifdef TOPAY_STAMPS

@@ -11,11 +11,12 @@
 #include "topay_jps.h"
 
 // Waves per SIMD a kernel is built for (OCC): the register allocator leaves room for that many -- 512 / OCC registers
-// (VGPR + AGPR) per lane.  The two commonest launch classes (N <= 15) run two waves per SIMD since round 4: the solve is
-// bound by the latency of its serial chains (banded LU, substitutions, the reductions of the two-loop recursion), which a
-// second resident wave hides; that needs every device function of their call graph inside 256 registers, so the
-// non-inlined ones (manipulator_block, minco_generate, eval_cost_grad, the in-solve gate) are templated on OCC and the
-// attribute below reaches them per instantiation.
+// (VGPR + AGPR) per lane.  Since round 4 every solve / evaluation kernel is built for OCC = 2: 256 registers, which the
+// allocator takes as 256 VGPRs and no AGPRs.  The serial chains of a solve (banded LU, substitutions, hand-offs) overlap
+// with the second resident wave; the sample body and the two-loop recursion are bound by VALU issue and do not
+// (DESIGN.md section 9).  Every device function of the call graph has to fit, so the non-inlined ones (manipulator_block,
+// minco_generate_mw, eval_cost_grad_mw, the in-solve gate) are templated on OCC and the kernel's attribute reaches them per
+// instantiation.
 using namespace topay;
 
 #ifndef TOPAY_CPU_EMU
