@@ -1,2 +1,4 @@
 #!/bin/bash
-for l in r3_stamps stamps stamps_la2; do echo "== $l"; TOPAY_LIB=$PWD/tools/libs/libtopay_$l.so timeout 300 python3 tools/gpu_stamps.py 2>&1 | tail -22; done
+# per-phase shader-clock stamps of the evaluation (diagnostics build) at one and at two resident waves per SIMD
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for S in 128 512; do echo "== S=$S"; TOPAY_LIB=tools/libs/libtopay_stamps.so timeout 900 python3 tools/gpu_stamps.py $S 2>&1 | tail -22; done

@@ -4,7 +4,7 @@ import numpy as np
 from harness import workload as wl
 from topay_amd import api
 gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB", "topay_amd/lib/libtopay_hip_stamps.so"))
-names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]
+names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "rows+sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]
 for S in (int(sys.argv[1]) if len(sys.argv) > 1 else 128,):
     w2, lens2, paths2, scen2 = wl.cuboids_batch(S, 8)
     gpu.set_map(w2.origin, w2.res, w2.dims, w2.min_b, w2.max_b, w2.esdf2d, w2.esdf3d)
@@ -31,5 +31,9 @@ try:
     gpu.L.topay_debug_mani_stamps(arr)
     v = np.array(list(arr), dtype=float)
     print("manipulator phases (share):", dict(zip(["sincos", "walk1", "pairs", "esdf", "walks2", "limits"], np.round(v[:6] / v[:6].sum(), 3))))
+    if v[7] > 0:
+        calls = v[7] / 12.0
+        print("manipulator block: %.0f cycles per call, ESDF loop %.0f, of which waiting for the gathers of the sphere being finished %.0f (%.1f %% of the block)"
+              % (v[:6].sum() / calls, v[3] / calls, v[6] / calls, 100.0 * v[6] / v[:6].sum()))
 except Exception as e:
     print("no mani stamps", e)

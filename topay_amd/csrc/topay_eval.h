@@ -816,6 +816,20 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       }
     }
     double d, gx, gy, gz;
+#ifdef TOPAY_STAMPS
+    {
+      // exposed latency of this sphere's eight gathers: cycles until they have returned (the 8 min(LA, spheres left)
+      // issued after them may stay in flight), measured where the first of them is needed
+      const long long w0_ = (long long)__builtin_amdgcn_s_memtime();
+      constexpr int FULL = 8 * LA;   // s_waitcnt vmcnt(n): expcnt / lgkmcnt fields left at their maxima
+      const int left = TOPAY_NSPH - 1 - k;
+      if (left >= LA) __builtin_amdgcn_s_waitcnt(0x0f70 | (FULL & 15) | ((FULL >> 4) << 14));
+      else if (left == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 8);
+      else __builtin_amdgcn_s_waitcnt(0x0f70);
+      const long long w1_ = (long long)__builtin_amdgcn_s_memtime();
+      if (blockIdx.x == 0 && threadIdx.x == 0) { g_mani_stamps[6] += w1_ - w0_; g_mani_stamps[7] += 1; }
+    }
+#endif
     esdf3d_finish(M, rq[k % (LA + 1)], d, gx, gy, gz);
     const double viola = P.sph_viol[k] - d * 10.0;
     if (viola > 0) {

@@ -214,6 +214,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     }
   }
   wg_barrier<NW>();
+  STAMP(C, 0);  // fills
   // LU without pivoting on wave 0 (banded_system.hpp:66-91); the other waves wait at the barrier below
   if (wave == 0) {
     const int t = lane / 7 + 1, u = lane - (lane / 7) * 7;
@@ -232,6 +233,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     }
   }
   wg_barrier<NW>();
+  STAMP(C, 1);  // LU
   for (int t = tid; t < rows; t += NT) rdiag[t] = 1.0 / BAND(t, t);
   wg_barrier<NW>();
   if (tid < 9) {
@@ -241,6 +243,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   for (int t = tid; t < 14 * rows; t += NT) c_lu[t] = c_X[t];
   C.cl_in_lds = 1;
   wg_barrier<NW>();
+  STAMP(C, 2);  // substitutions, LU stash
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +342,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const double wA = STAGE == 1 ? P.s1_acc_weight : P.s2_acc_weight;
   const double wD = STAGE == 1 ? P.s1_domega_weight : P.s2_domega_weight;
 
+  STAMP(C, 3);  // jerk, row bookkeeping
   // =========================== sweep 1, phase A: Simpson panels, prefix inside each pass, pass totals
   for (int k = 0; k < nround; k++) {
     const int pass = k * NW + wave;
@@ -452,6 +456,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     pc++;
   }
   if (NW == 1) lds_sync();   // (several waves: the barrier of the last round's cost exchange) piece-end positions are read below
+  STAMP(C, 4);  // sweep 1
 
   // ---- per-piece terms between the sweeps
   double cost_piece = 0.0;
@@ -499,6 +504,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const bool bad = (STAGE == 2) && !(fabs(penalty_cost) <= 1.79769313486231570e308);
   const double f_total = jerk_cost + (bad ? 1.0e+22 : penalty_cost) + time_cost;
 
+  STAMP(C, 5);  // per-piece terms, cost
   if (skip_body) return f_skip;
   if (!gate.needs(f_total)) return f_total;
 
@@ -959,6 +965,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     wg_barrier<NW>();
   }
 
+  STAMP(C, 6);  // gradient rows to the row threads, sweep 2
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
   lds_dp band = c_X;
   lds_dp rdiag = c_X + 13 * rows;
@@ -1016,6 +1023,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     band_sweep<3>(c_adj + tid * rows, band, rdiag, rows);
   }
   wg_barrier<NW>();
+  STAMP(C, 7);  // adjoint solve
   // ---- dJ/dT correction  gdT(i) += sum(B1 .* adj rows 6i+3..6i+8) — minco.hpp:1016-1067
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -1074,6 +1082,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   }
   if (tid == 0) c_g[3 * N - 2] = c_adj[1 * rows + rows - 3];
   __syncthreads();
+  STAMP(C, 8);  // dJ/dT correction, chain rule
   return f_total;
 }
 
