@@ -4,7 +4,7 @@ candidates (launch classes N <= 42 / 64 / 128).
   * An evaluation is order-identical whatever the number of waves: for every N <= 64 the 2- and 4-wave kernels must
     return, bit for bit, what the one-wave kernel returns (cost, gradient, end-point error) -- both stages, ordinary
     points and the rare paths (joint velocity / acceleration rows, mean-time band, non-finite cost).
-  * N = 65..128 exists only on four waves (compact LDS layout from ~85 pieces on): per-evaluation parity against the
+  * N = 65..128 exists only on four waves: per-evaluation parity against the
     oracle, capped solves against the oracle, and whole solves against the oracle's solver logic in the device's
     vector order (64 x waves threads, topay_class_of) fed with the device's evaluations -- bit for bit.
 The CPU half runs the kernel sources in the lane emulator (its waves really run out of step between workgroup
@@ -97,7 +97,7 @@ def test_class_table():
 
 def test_multiwave_evaluation_is_order_identical_on_cpu(cuboids_small):
     """Kernel sources in the lane emulator: candidates of 4..11 pieces and a 33-piece one through the 1-, 2- and 4-wave
-    kernels (bit-identical), a 95-piece (full LDS layout) and a 126-piece one (compact layout) through four waves
+    kernels (bit-identical), a 95-piece and a 126-piece one through four waves
     against the oracle."""
     cs = cuboids_small
     rng = np.random.default_rng(5)
@@ -133,7 +133,7 @@ def test_multiwave_evaluation_is_order_identical_on_gpu(cuboids_small):
     N = gpu.n_pieces()
     assert N[2] == 33 and N[5] == 64 and N[6] == 65 and N[10] == 128 and N[11] == 0     # 129 pieces: refused
     _check_eval(gpu, cs, long_, rng)
-    # GPU == lane emulator, every bit, on a four-wave evaluation with the compact layout
+    # GPU == lane emulator, every bit, on a four-wave evaluation
     emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
     set_map(emu, cs["world"])
     emu.set_init_traj(np.array([len(long_[9])], dtype=np.int32), long_[9])

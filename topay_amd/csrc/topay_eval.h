@@ -402,10 +402,9 @@ struct EvalCtx {
   // several waves per trajectory (topay_eval_mw.h): thread index in the workgroup, wave index, small cross-wave scratch
   int tid, wave;
   lds_dp red;    // [8] partial sums of a workgroup reduction (two phases) | [64] pass totals | [2][NW][64] per-round costs | [NW] masks
-  lds_dp adj;    // [9][rows] right-hand sides / solution of the adjoint solve (== cL in the compact layout)
-  glb_dp coefg;  // HBM copy of the coefficients (the candidate's result block), read by the dJ/dT correction in the compact layout
-  int compact;
-  int cl_in_lds; // the coefficients of the last evaluation are still in C.cL (0: compact layout after a gradient phase -- they are in coefg)
+  lds_dp adj;    // [9][rows] right-hand sides / solution of the adjoint solve (the coefficients' block: == cL)
+  glb_dp coefg;  // HBM copy of the coefficients (the candidate's result block), read by the dJ/dT correction
+  int cl_in_lds; // the coefficients of the last evaluation are still in C.cL (0 after a gradient phase -- they are in coefg)
   // LDS
   lds_dp cL;     // [9][rows]  MINCO coefficients, column d contiguous (the reference's col-major c)
   lds_dp Tp;     // [5][N]     T, T^2..T^5
@@ -503,60 +502,117 @@ struct GradGate {
 //   MODE 2  U^T x = b   (adjoint, forward):   b(i) -= A(j,i) (b(j)/A(j,j)),   i = j+1..j+6 ; stores b(j)/A(j,j)
 //   MODE 3  L^T x = b   (adjoint, backward):  b(i) -= A(j,i) b(j),            i = j-1..j-6
 // rows = 6N is a multiple of 6: blocks of six steps with compile-time register indices.
+//
+// The factors are NOT resident in LDS (round 4): the band (84 N doubles) beside the right-hand sides (54 N) was the
+// peak of the LDS plan and decided how many trajectories share a compute unit.  They stream from the candidate's LU
+// block in HBM ([14][rows]: 13 diagonals, then the reciprocal diagonal; written once per evaluation by the
+// factorisation) through two windows of 7 rows x 30 columns in LDS: a chunk is 24 steps (four blocks), all 64 lanes
+// of the wave request the next chunk's window, the nine owner lanes sweep the current one, the requested values are
+// written to the other window.  Window row r holds diagonal D0 + r (D0 = 7: the lower factor, modes 0 and 3; D0 = 0:
+// the upper factor, modes 1 and 2), row 6 the reciprocal diagonal; window column = matrix column - clo.  Which value
+// feeds which multiply-subtract is unchanged.
+#define TOPAY_SWEEP_CHUNK 24
+#define TOPAY_SWEEP_WCOLS 30
+#define TOPAY_SWEEP_WIN (7 * TOPAY_SWEEP_WCOLS)   // doubles per window; the sweeps use two
 template <int MODE>
-__device__ __forceinline__ void band_sweep(lds_dp v, lds_cdp band, lds_cdp rdiag, int rows) {
+__device__ __forceinline__ void band_sweep(lds_dp v, bool owner, glb_cdp lu, lds_dp win, int rows, int lane) {
   constexpr bool FWD = (MODE == 0 || MODE == 2);
   constexpr bool SCALE = (MODE == 1 || MODE == 2);
+  constexpr int D0 = (MODE == 0 || MODE == 3) ? 7 : 0;
+  constexpr int CH = TOPAY_SWEEP_CHUNK, WC = TOPAY_SWEEP_WCOLS, WIN = TOPAY_SWEEP_WIN;
+  constexpr int NEL = (SCALE ? 7 : 6) * WC;      // window elements in use
+  constexpr int NQ = (NEL + 63) / 64;            // per lane
   double w[6];
-  double x;
-  if (FWD) {
-    x = v[0];
+  double x = 0.0;
 #pragma unroll
-    for (int t = 0; t < 6; t++) w[t] = v[1 + t];
-  } else {
-    x = v[rows - 1];
+  for (int t = 0; t < 6; t++) w[t] = 0.0;
+  if (owner) {
+    if (FWD) {
+      x = v[0];
 #pragma unroll
-    for (int t = 0; t < 6; t++) w[t] = v[rows - 2 - t];
+      for (int t = 0; t < 6; t++) w[t] = v[1 + t];
+    } else {
+      x = v[rows - 1];
+#pragma unroll
+      for (int t = 0; t < 6; t++) w[t] = v[rows - 2 - t];
+    }
   }
-  for (int b0 = 0; b0 < rows; b0 += 6) {
-    // everything the block reads from LDS, issued up front: 36 coefficients, 6 scales, 6 incoming entries
-    double cf[6][6], sc[6], nw[6];
+  const int nchunk = (rows + CH - 1) / CH;
+  // first matrix column of chunk k's window
+  auto chunk_clo = [&](int k) { return FWD ? CH * k : rows - 1 - CH * k - (WC - 1); };
+  auto request = [&](int k, double (&q)[NQ]) {
+    const int clo = chunk_clo(k);
 #pragma unroll
-    for (int u = 0; u < 6; u++) {
-      const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
+    for (int u = 0; u < NQ; u++) {
+      const int e = lane + 64 * u;
+      const int r = e / WC, cc = e - r * WC;
+      int c = clo + cc;
+      c = c < 0 ? 0 : (c > rows - 1 ? rows - 1 : c);   // columns outside the matrix only ever feed rows that do not exist
+      const int d = (r < 6 ? D0 + r : 13);
+      q[u] = lu[(d < 14 ? d : 13) * rows + c];         // (e >= NEL: a valid address, the value is dropped)
+    }
+  };
+  auto deposit = [&](int k, const double (&q)[NQ]) {
+    lds_dp wb = win + (k & 1) * WIN;
 #pragma unroll
-      for (int t = 1; t <= 6; t++) {
-        int idx;
-        if (MODE == 0) idx = (6 + t) * rows + j;            // A(j+t, j)
-        else if (MODE == 1) idx = (6 - t) * rows + j;       // A(j-t, j)
-        else if (MODE == 2) idx = (6 - t) * rows + j + t;   // A(j, j+t)
-        else idx = (6 + t) * rows + j - t;                  // A(j, j-t)
-        // Unconditional loads (a predicated load costs more than the arithmetic here).  The index stays inside the
-        // 13 x rows band array for every (j, t); where row i = j +- t falls outside the matrix the value read is a
-        // never-written zero (modes 0, 1) or an unrelated entry (modes 2, 3) and only ever feeds window slots of
-        // rows that do not exist and are never stored.
-        cf[u][t - 1] = band[idx];
+    for (int u = 0; u < NQ; u++) {
+      const int e = lane + 64 * u;
+      if (e < NEL) wb[e] = q[u];
+    }
+  };
+  double q[NQ];
+  request(0, q);
+  deposit(0, q);
+  lds_sync();
+  for (int k = 0; k < nchunk; k++) {
+    const bool more = k + 1 < nchunk;
+    if (more) request(k + 1, q);
+    if (owner) {
+      lds_cdp wb = win + (k & 1) * WIN;
+      const int clo = chunk_clo(k);
+#pragma unroll 1
+      for (int b0 = CH * k; b0 < CH * (k + 1) && b0 < rows; b0 += 6) {
+        // everything the block reads from LDS, issued up front: 36 coefficients, 6 scales, 6 incoming entries
+        double cf[6][6], sc[6], nw[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
+#pragma unroll
+          for (int t = 1; t <= 6; t++) {
+            int idx;
+            if (MODE == 0) idx = (t - 1) * WC + (j - clo);            // A(j+t, j)
+            else if (MODE == 1) idx = (6 - t) * WC + (j - clo);       // A(j-t, j)
+            else if (MODE == 2) idx = (6 - t) * WC + (j + t - clo);   // A(j, j+t)
+            else idx = (t - 1) * WC + (j - t - clo);                  // A(j, j-t)
+            // Unconditional reads.  Where row i = j +- t falls outside the matrix the value is a never-written zero of
+            // the band (modes 0, 1) or an unrelated entry (modes 2, 3) and only ever feeds window slots of rows that
+            // do not exist and are never stored.
+            cf[u][t - 1] = wb[idx];
+          }
+          if (SCALE) sc[u] = wb[6 * WC + (j - clo)];
+          int in = FWD ? j + 7 : j - 7;
+          in = in < 0 ? 0 : (in > rows - 1 ? rows - 1 : in);
+          nw[u] = v[in];
+        }
+        double xo[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const double xs = SCALE ? x * sc[u] : x;
+          xo[u] = xs;
+#pragma unroll
+          for (int t = 0; t < 6; t++) w[(u + t) % 6] -= cf[u][t] * xs;
+          x = w[u % 6];
+          w[u % 6] = nw[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
+          v[j] = xo[u];
+        }
       }
-      if (SCALE) sc[u] = rdiag[j];
-      int in = FWD ? j + 7 : j - 7;
-      in = in < 0 ? 0 : (in > rows - 1 ? rows - 1 : in);
-      nw[u] = v[in];
     }
-    double xo[6];
-#pragma unroll
-    for (int u = 0; u < 6; u++) {
-      const double xs = SCALE ? x * sc[u] : x;
-      xo[u] = xs;
-#pragma unroll
-      for (int t = 0; t < 6; t++) w[(u + t) % 6] -= cf[u][t] * xs;
-      x = w[u % 6];
-      w[u % 6] = nw[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 6; u++) {
-      const int j = FWD ? b0 + u : rows - 1 - (b0 + u);
-      v[j] = xo[u];
-    }
+    if (more) deposit(k + 1, q);
+    lds_sync();
   }
 }
 

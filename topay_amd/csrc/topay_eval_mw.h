@@ -77,11 +77,12 @@ __device__ __forceinline__ double wg_max(lds_dp red, int& phase, int wave, doubl
   return m;
 }
 
-// LDS of an NW-wave workgroup: coefficients | [adjoint block] | T powers | dJ/dT | per-piece scratch | power table |
-// cross-wave scratch | union (band + reciprocal diagonal | positional gradients + one pass buffer per wave).
-// One wave (round 4): LDS is what decides how many trajectories share a compute unit once the kernels fit two waves per
-// SIMD, so the one-wave plan holds nothing it can do without -- always the compact layout (the adjoint solve runs in the
-// coefficients' block), a pass buffer of 7 rows (the gradient rows of a pass are handed to the row lanes in two halves),
+// LDS of an NW-wave workgroup: coefficients | T powers | dJ/dT | per-piece scratch | power table | cross-wave scratch |
+// union (band + reciprocal diagonal | positional gradients + one pass buffer per wave).  LDS is what decides how many
+// trajectories share a compute unit once the kernels fit two waves per SIMD (round 4), so the adjoint solve runs in the
+// coefficients' block for every class (they go to the candidate's result block in HBM first; a block of its own for the
+// adjoint cost the four-wave classes 18 / 27 KB at N = 42 / 63 and the bench 5.7 %, docs/EXPERIMENTS.md).
+// One wave: the plan holds nothing it can do without -- a pass buffer of 7 rows (the gradient rows of a pass are handed to the row lanes in two halves),
 // no per-round cost exchange (the cost of a pass stays in its lane's register), pass totals sized by the passes there are,
 // and the boundary conditions read from HBM where they are used (once per evaluation): 148 N + 264 doubles for N >= 8,
 // 14 / 20 / 27 / 40 KB at N = 10 / 15 / 21 / 32 (rounds 1-3: 21 / 27 / 36 / 54 KB).
@@ -91,30 +92,33 @@ __host__ __device__ __forceinline__ int mw_npass(int Nmax) { return (TOPAY_EP * 
 __host__ __device__ __forceinline__ int mw_misc_doubles(int Nmax, int NW) {
   return 8 + 2 * mw_npass(Nmax) + (NW > 1 ? 2 * NW * 64 : 0) + 8;
 }
-__host__ __device__ __forceinline__ int lds_doubles_mw(int Nmax, int NW, int compact) {
+__host__ __device__ __forceinline__ int lds_doubles_mw(int Nmax, int NW) {
   const int rows = 6 * Nmax;
-  const int xr = 14 * rows, sr = 26 * Nmax + mw_pb_rows(NW) * 64 * NW;
-  return 9 * rows * (compact ? 1 : 2) + 5 * Nmax + Nmax + 4 * (Nmax + 1) + 156 + mw_misc_doubles(Nmax, NW) + (xr > sr ? xr : sr);
+  // the big block: band + reciprocal diagonal while the system is factorised | afterwards the coefficients (also the adjoint's
+  // right-hand sides / solution) and, behind them, the positional gradients + pass buffers (the substitutions' windows and the
+  // solver's alpha array use the same space)
+  const int lu = 14 * rows, sw = 9 * rows + 26 * Nmax + mw_pb_rows(NW) * 64 * NW;
+  return 5 * Nmax + Nmax + 4 * (Nmax + 1) + 156 + mw_misc_doubles(Nmax, NW) + (lu > sw ? lu : sw);
 }
-__device__ __forceinline__ void carve_mw(EvalCtx& C, lds_dp base, int Nmax, int NW, int compact) {
+__device__ __forceinline__ void carve_mw(EvalCtx& C, lds_dp base, int Nmax, int NW) {
   const int rows = 6 * Nmax;
-  C.cL = base;
-  lds_dp p = base + 9 * rows;
-  if (compact) C.adj = C.cL;
-  else { C.adj = p; p += 9 * rows; }
-  C.gC = C.adj;
+  lds_dp p = base;
   C.Tp = p; p += 5 * Nmax;
   C.gdT = p; p += Nmax;
   C.pcs = p; p += 4 * (Nmax + 1);
   C.pw = p; p += 156;
   C.red = p; p += mw_misc_doubles(Nmax, NW);
-  C.X = p;
-  C.compact = compact;
+  C.cL = p;                // (the band of the factorisation starts here too)
+  C.adj = C.cL;
+  C.gC = C.adj;
+  C.X = p + 9 * rows;
   C.npass_lds = mw_npass(Nmax);
 }
 
 // MINCO generate for an NW-wave workgroup: fills divided over all threads, LU on wave 0 (the pivots are a serial chain),
-// substitutions on lanes 0..8 of wave 0.  Same statements as minco_generate().
+// substitutions on lanes 0..8 of wave 0 (topay_eval.h: band_sweep).  The band lives in the block the coefficients take
+// afterwards: factorise, stash the factors in the candidate's LU block in HBM (the adjoint needs them again anyway), fill the
+// right-hand sides over the band, substitute with the factors streamed back through two small windows.
 template <int NW, int OCC>
 __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   constexpr int NT = 64 * NW;
@@ -127,9 +131,9 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   const DevParams& P = g_P;
   const int tid = C.tid, lane = C.lane, wave = __builtin_amdgcn_readfirstlane(C.wave);
   const int N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
-  lds_dp band = c_X;
-  lds_dp rdiag = c_X + 13 * rows;
   lds_dp cL = C.cL;
+  lds_dp band = cL;                 // [13][rows] while the system is factorised, then the coefficients' block
+  lds_dp rdiag = cL + 13 * rows;
   glb_cdp Tau = c_x;
   glb_cdp Theta = c_x + N;
   glb_cdp Arc = c_x + 2 * N - 1;
@@ -159,7 +163,6 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     bc_v[4] = c_tl[1 * 9 + d]; bc_v[5] = c_tl[2 * 9 + d];
   }
   for (int t = tid; t < 13 * rows; t += NT) band[t] = 0.0;
-  for (int t = tid; t < 9 * rows; t += NT) cL[t] = 0.0;
   if (tid < N) {
     double T1 = expC2(tau_v);  // calTfromTau, moma_traj_opt.h:778-786
     double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
@@ -195,24 +198,6 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
     BAND(R0 - 2, R0 - 1) = 5 * T4;
     BAND(R0 - 1, R0 - 4) = 2; BAND(R0 - 1, R0 - 3) = 6 * T1; BAND(R0 - 1, R0 - 2) = 12 * T2; BAND(R0 - 1, R0 - 1) = 20 * T3;
   }
-  if (tid < 9) {
-    const int d = tid;
-    cL[d * rows + 0] = bc_v[0];
-    cL[d * rows + 1] = bc_v[1];
-    cL[d * rows + 2] = bc_v[2];
-    cL[d * rows + rows - 3] = bc_v[3];
-    cL[d * rows + rows - 2] = bc_v[4];
-    cL[d * rows + rows - 1] = bc_v[5];
-  }
-#pragma unroll
-  for (int u = 0; u < NI; u++) {
-    const int t = tid + NT * u;
-    if (t < 9 * (N - 1)) {
-      const int i = t / 9, d = t - 9 * i;
-      const int dq = d >= 2 ? d - 2 : 0;
-      cL[d * rows + 6 * i + 5] = d >= 2 ? sigmoidC2(inner_v[u], P.joint_pos_limit_max[dq]) : inner_v[u];
-    }
-  }
   wg_barrier<NW>();
   STAMP(C, 0);  // fills
   // LU without pivoting on wave 0 (banded_system.hpp:66-91); the other waves wait at the barrier below
@@ -236,11 +221,38 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   STAMP(C, 1);  // LU
   for (int t = tid; t < rows; t += NT) rdiag[t] = 1.0 / BAND(t, t);
   wg_barrier<NW>();
+  // factors to the candidate's LU block; nothing of the band is read from LDS after this
+  for (int t = tid; t < 14 * rows; t += NT) c_lu[t] = band[t];
+  wave_global_sync();
+  wg_barrier<NW>();
+  // right-hand sides over the band: boundary conditions and inner points, zero elsewhere
+  for (int t = tid; t < 9 * rows; t += NT) cL[t] = 0.0;
+  wg_barrier<NW>();
   if (tid < 9) {
-    band_sweep<0>(cL + tid * rows, band, rdiag, rows);
-    band_sweep<1>(cL + tid * rows, band, rdiag, rows);
+    const int d = tid;
+    cL[d * rows + 0] = bc_v[0];
+    cL[d * rows + 1] = bc_v[1];
+    cL[d * rows + 2] = bc_v[2];
+    cL[d * rows + rows - 3] = bc_v[3];
+    cL[d * rows + rows - 2] = bc_v[4];
+    cL[d * rows + rows - 1] = bc_v[5];
   }
-  for (int t = tid; t < 14 * rows; t += NT) c_lu[t] = c_X[t];
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int t = tid + NT * u;
+    if (t < 9 * (N - 1)) {
+      const int i = t / 9, d = t - 9 * i;
+      const int dq = d >= 2 ? d - 2 : 0;
+      cL[d * rows + 6 * i + 5] = d >= 2 ? sigmoidC2(inner_v[u], P.joint_pos_limit_max[dq]) : inner_v[u];
+    }
+  }
+  wg_barrier<NW>();
+  if (wave == 0) {
+    const bool owner = lane < 9;
+    const lds_dp mine = cL + (owner ? lane : 8) * rows;
+    band_sweep<0>(mine, owner, (glb_cdp)c_lu, c_X, rows, lane);
+    band_sweep<1>(mine, owner, (glb_cdp)c_lu, c_X, rows, lane);
+  }
   C.cl_in_lds = 1;
   wg_barrier<NW>();
   STAMP(C, 2);  // substitutions, LU stash
@@ -274,7 +286,6 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const lds_dp c_red = uniform_ptr(C.red);
   const lds_dp c_adj = uniform_ptr(C.adj);
   const glb_dp c_coefg = uniform_ptr(C.coefg);
-  const bool compact = __builtin_amdgcn_readfirstlane(C.compact) != 0;
 
   const DevParams& P = g_P;
   const int lane = C.lane, tid = C.tid, wave = __builtin_amdgcn_readfirstlane(C.wave);
@@ -967,8 +978,6 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
 
   STAMP(C, 6);  // gradient rows to the row threads, sweep 2
   // ---- total dJ/dC = jerk part (minco.hpp:951-976) + penalty part; adjoint solve (banded_system.hpp:123-145)
-  lds_dp band = c_X;
-  lds_dp rdiag = c_X + 13 * rows;
   double tot[RMAX][9];
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -989,27 +998,12 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
   }
-  if (compact) {
-    // the adjoint solve takes the coefficients' LDS block: they go to the candidate's result block in HBM first (which
-    // is where a solve that ends here leaves them anyway); the dJ/dT correction below reads them back from there
-    for (int t = tid; t < 9 * rows; t += NT) c_coefg[t] = cL[t];
-    C.cl_in_lds = 0;
-    __syncthreads();
-  }
-  // reload of the LU factors (the union region is free), eight loads in flight per thread
-  for (int t0 = tid; t0 < 14 * rows; t0 += NT * 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + NT * u;
-      v[u] = c_lu[t < 14 * rows ? t : 14 * rows - 1];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + NT * u;
-      if (t < 14 * rows) c_X[t] = v[u];
-    }
-  }
+  // the adjoint solve takes the coefficients' LDS block: they go to the candidate's result block in HBM first (which
+  // is where a solve that ends here leaves them anyway); the dJ/dT correction below reads them back from there
+  for (int t = tid; t < 9 * rows; t += NT) c_coefg[t] = cL[t];
+  C.cl_in_lds = 0;
+  __syncthreads();
+  // (the LU factors stream from the candidate's LU block through the windows of band_sweep: nothing to reload)
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
     if (ract[r]) {
@@ -1018,9 +1012,11 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     }
   }
   wg_barrier<NW>();
-  if (tid < 9) {
-    band_sweep<2>(c_adj + tid * rows, band, rdiag, rows);
-    band_sweep<3>(c_adj + tid * rows, band, rdiag, rows);
+  if (wave == 0) {
+    const bool owner = lane < 9;
+    const lds_dp mine = c_adj + (owner ? lane : 8) * rows;
+    band_sweep<2>(mine, owner, (glb_cdp)c_lu, c_X, rows, lane);
+    band_sweep<3>(mine, owner, (glb_cdp)c_lu, c_X, rows, lane);
   }
   wg_barrier<NW>();
   STAMP(C, 7);  // adjoint solve
@@ -1039,14 +1035,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
         const double T1 = c_Tp[pi], T2 = c_Tp[N + pi], T3 = c_Tp[2 * N + pi], T4 = c_Tp[3 * N + pi];
 #pragma unroll
         for (int d = 0; d < 9; d++) {
-          double c1, c2, c3, c4, c5;
-          if (compact) {
-            glb_cdp cg = c_coefg + d * rows + 6 * pi;
-            c1 = cg[1]; c2 = cg[2]; c3 = cg[3]; c4 = cg[4]; c5 = cg[5];
-          } else {
-            lds_cdp c = cL + d * rows + 6 * pi;
-            c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
-          }
+          glb_cdp cg = c_coefg + d * rows + 6 * pi;   // (the LDS block holds the adjoint now)
+          const double c1 = cg[1], c2 = cg[2], c3 = cg[3], c4 = cg[4], c5 = cg[5];
           double b;
           if (br == 0) b = -(24.0 * c4 + 120.0 * T1 * c5);
           else if (br == 1) b = -120.0 * c5;
@@ -1056,7 +1046,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
           part += b * c_adj[d * rows + row];
         }
       }
-      rdiag[row] = part;
+      c_X[row] = part;   // (the windows of the sweeps are dead)
     }
   }
   wg_barrier<NW>();
@@ -1064,8 +1054,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   if (tid < N) {
     const int i = tid;
     double s = 0.0;
-    if (i < N - 1) { for (int r = 0; r < 6; r++) s += rdiag[6 * i + 3 + r]; }
-    else { for (int r = 0; r < 3; r++) s += rdiag[rows - 3 + r]; }
+    if (i < N - 1) { for (int r = 0; r < 6; r++) s += c_X[6 * i + 3 + r]; }
+    else { for (int r = 0; r < 3; r++) s += c_X[rows - 3 + r]; }
     gdT_tot = jerk_gdT + c_gdT[i] + s;
   }
   // ---- chain rule to the decision variables — moma_traj_opt.cpp:936-948

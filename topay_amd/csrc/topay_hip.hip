@@ -110,8 +110,8 @@ static const int kBigFirst = 4;   // the classes of long candidates (N > 32) sta
 // Kernel of a launch class: rows per thread and waves per trajectory select the template; the LDS is sized by the
 // longest candidate actually in the class.  The classes of long candidates have a one-wave and a several-waves variant
 // (TOPAY_MW_C4 / TOPAY_MW_C5 = waves per trajectory for N <= 42 / N <= 64; N <= 128 always runs on four waves).
-typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int, int);
-typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int, int);
+typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
+typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
 struct ClassDef {
   int max_n, rmax, nw;
   solve_kernel_t solve;
@@ -142,13 +142,18 @@ static const ClassDef* class_table() {
   return tab;
 }
 static const int kLdsDoublesPerCU = 160 * 1024 / 8;
-// compact LDS layout (topay_eval_mw.h) when the full one does not fit a compute unit
-static int class_compact(const ClassDef& cd, int nm) {
-  if (cd.nw == 1) return 1;   // one wave: LDS is what limits how many workgroups share a compute unit
-  return lds_doubles_mw(nm, cd.nw, 0) + 8 + 48 > kLdsDoublesPerCU ? 1 : 0;
-}
 static size_t class_lds_bytes(const ClassDef& cd, int nm) {
-  const int d = lds_doubles_mw(nm, cd.nw, class_compact(cd, nm));
+  int d = lds_doubles_mw(nm, cd.nw);
+  // experiments build: TOPAY_LDS_PAD="<max_n of a class>:<doubles>[,...]" asks for more LDS than the class needs (what a
+  // workgroup less per compute unit costs)
+  if (const char* e = exp_env("TOPAY_LDS_PAD")) {
+    for (const char* q = e; q && *q;) {
+      int mn = 0, add = 0;
+      if (sscanf(q, "%d:%d", &mn, &add) == 2 && mn == cd.max_n) d += add;
+      q = strchr(q, ',');
+      if (q) q++;
+    }
+  }
   return (size_t)(d + 8 + 48) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [48]
 }
 
@@ -1146,9 +1151,8 @@ static hipError_t set_kernel_attributes(int device) {
     (void)device;
     hipError_t e = hipSuccess;
     const ClassDef* ct = class_table();
-    // The whole LDS of a compute unit for every kernel: the request of a launch is not monotone in the longest candidate
-    // (the four-wave class switches to the compact layout where the full one stops fitting, so N = 95 asks for more than
-    // N = 128), and an attribute below a launch's request is an error on a runtime that enforces it.
+    // The whole LDS of a compute unit for every kernel: an attribute below a launch's request is an error on a runtime
+    // that enforces it, and nothing is gained by asking for less.
     const int lds = kLdsDoublesPerCU * 8;
     for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
       e = hipFuncSetAttribute((const void*)ct[k].solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1226,13 +1230,12 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
     }
     off += nk;
     const size_t lds = class_lds_bytes(ct[k], nm);
-    const int compact = class_compact(ct[k], nm);
     if (k == topay_ctx::NBUCKET - 2 && !c->cls[topay_ctx::NBUCKET - 1].empty() && c->bstream[k] == c->stream)
       HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));   // both long classes in one batch: they must not serialise
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
-    if constexpr (EVAL) hipLaunchKernelGGL(ct[k].eval, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm, compact);
-    else hipLaunchKernelGGL(ct[k].solve, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, nm, compact);
+    if constexpr (EVAL) hipLaunchKernelGGL(ct[k].eval, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+    else hipLaunchKernelGGL(ct[k].solve, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, nm);
     HIPCHK(hipGetLastError());
     if (st != c->stream) HIPCHK(hipEventRecord(c->bevent[k], st));
     launches++;
@@ -2105,7 +2108,7 @@ static topay_status eval_one(topay_ctx* c, int stage, int i, const double* x, co
   if ((s = push_params(c)) != TOPAY_OK) return s;
   HIPCHK(set_kernel_attributes(c->device));
   if (force_nw > 0) HIPCHK(hipFuncSetAttribute((const void*)cd.eval, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoublesPerCU * 8));
-  hipLaunchKernelGGL(cd.eval, dim3(1), dim3(64 * cd.nw), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N, class_compact(cd, N));
+  hipLaunchKernelGGL(cd.eval, dim3(1), dim3(64 * cd.nw), lds, c->stream, d, (const DevMap*)c->dmaps.p, stage | (commit ? 16 : 0), 1, N);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   tmp.release();

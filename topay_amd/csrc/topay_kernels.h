@@ -48,12 +48,12 @@ __device__ __forceinline__ long long uniform_i64(long long v) {
 
 // LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
 template <int NW>
-__host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds, int compact) {
-  return lds_doubles_mw(Nmax_lds, NW, compact);
+__host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds) {
+  return lds_doubles_mw(Nmax_lds, NW);
 }
 
 template <int RMAX, int NW>
-__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds, int compact) {
+__device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, int Nmax_lds) {
   constexpr int NT = 64 * NW;
   C.tid = threadIdx.x;
   C.lane = threadIdx.x & 63;
@@ -61,8 +61,8 @@ __device__ __forceinline__ void load_ctx(EvalCtx& C, const DevBatch& Bt, int b, 
   C.N = __builtin_amdgcn_readfirstlane(Bt.N[b]);  // wave-uniform: keep it (and what derives from it) in scalar registers
   C.rows = 6 * C.N;
   C.n = 10 * C.N - 8;
-  C.red = nullptr; C.adj = nullptr; C.compact = 0; C.cl_in_lds = 1;
-  carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW, compact);
+  C.red = nullptr; C.adj = nullptr; C.cl_in_lds = 1;
+  carve_mw(C, TOPAY_LDS_PTR, Nmax_lds, NW);
   fill_power_table(C.pw, C.lane);
   C.hd = (glb_cdp)(Bt.head + (size_t)b * 27);
   C.tl = (glb_cdp)(Bt.tail + (size_t)b * 27);
@@ -91,7 +91,7 @@ __device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& B
   constexpr int NT = 64 * NW;
   const int N = C.N, rows = C.rows;
   const long long po = uniform_i64(Bt.poff[b]);
-  // (compact layout after a gradient phase: the coefficients already sit in the result block, C.cL holds the adjoint)
+  // (after a gradient phase the coefficients already sit in the result block, C.cL holds the adjoint)
   if (C.cl_in_lds) {
     double* coef = Bt.coef + 54 * po;
     for (int t = C.tid; t < 9 * rows; t += NT) coef[t] = C.cL[t];
@@ -104,12 +104,12 @@ __device__ __forceinline__ void store_result(const EvalCtx& C, const DevBatch& B
 
 // test hook: one cost/gradient evaluation of trajectory order[blockIdx] at Bt.x with ALM state Bt.alm
 template <int RMAX, int NW, int OCC>
-__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int compact, int repeats) {
+__device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps, int stage, int Nmax_lds, int repeats) {
   const int b = Bt.order[blockIdx.x];
   const bool commit = (stage & 16) != 0;
   stage &= 15;
   EvalCtx C;
-  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
   const long long no = uniform_i64(Bt.noff[b]);
   C.x = (glb_cdp)(Bt.x + no);
@@ -146,7 +146,7 @@ template <int OCC>
 __device__ __noinline__ void feasibility_gate_in_solve(const FeasIO F, const TOPAY_GLB DevMap* mp) { feasibility_gate(F, mp); }
 
 template <int RMAX, int NW, int OCC>
-__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact, int b) {
+__device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int b) {
   constexpr int NT = 64 * NW;
   const unsigned long long t_begin = wall_clock64();
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
@@ -159,9 +159,9 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds, compact);
+  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds, compact);  // [8] past costs, then [48] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds);  // [8] past costs, then [48] solver state parked across an evaluation
   const long long no = uniform_i64(Bt.noff[b]);
   const int n = C.n;
   SolveIO S;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
 template <int RMAX, int NW, int OCC>
-__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int compact, int my_class) {
+__device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int my_class) {
   const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
   for (int cls = my_class; cls >= lowest; cls--) {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX, NW, OCC>(B, maps, Nmax_lds, compact, B.order[off + pos]);
+      solve_one<RMAX, NW, OCC>(B, maps, Nmax_lds, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -289,8 +289,8 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
 // not (nothing is shared between candidates).
 template <int RMAX, int NW, int OCC>
-__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int compact) {
-  drain_queues<RMAX, NW, OCC>(Bt, maps, Nmax_lds, compact, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
+__device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds) {
+  drain_queues<RMAX, NW, OCC>(Bt, maps, Nmax_lds, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
 // One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32, built for two waves per SIMD (256 registers, no
@@ -298,12 +298,12 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 // copies this image's compiler misplaces -- tools/isa_lint.py).  Several waves per trajectory (topay_eval_mw.h):
 // k_solve<rows per thread>w<waves>, rows <= 64 x waves x rows per thread, one wave per SIMD.
 #define TOPAY_SOLVE_KERNEL(NAME, R, W, OCC)                                                                         \
-  __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds, int compact) { \
-    solve_body<R, W, OCC>(Bt, maps, Nmax_lds, compact);                                                             \
+  __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds) { \
+    solve_body<R, W, OCC>(Bt, maps, Nmax_lds);                                                             \
   }
 #define TOPAY_EVAL_KERNEL(NAME, R, W, OCC)                                                                          \
-  __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds, int compact) { \
-    eval_body<R, W, OCC>(Bt, maps, stage, Nmax_lds, compact, repeats);                                              \
+  __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) { \
+    eval_body<R, W, OCC>(Bt, maps, stage, Nmax_lds, repeats);                                              \
   }
 #ifndef TOPAY_NO_KERNEL_TABLE   // (tools: a probe that instantiates one kernel of its own)
 TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, 2)
