@@ -45,3 +45,5 @@ for frac in (0.2, 0.4, 0.6):
 for lo, hi in ((4, 6), (7, 8), (9, 10), (11, 13), (14, 15), (16, 21), (22, 32), (33, 64)):
     q = (Nm >= lo) & (Nm <= hi)
     if q.any(): print(f"  N {lo}-{hi}: n {q.sum()}, us per trajectory {us[q].mean():.0f}, per eval {us[q].sum() / ev[q].sum():.1f}, evals {ev[q].mean():.0f}")
+print("  device-seconds by N (N: candidates, seconds):", " ".join(f"{n}:{(Nm == n).sum()},{us[Nm == n].sum() * 1e-6:.1f}" for n in range(16, 65) if (Nm == n).any()))
+

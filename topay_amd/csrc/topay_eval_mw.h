@@ -88,9 +88,11 @@ __device__ __forceinline__ double wg_max(lds_dp red, int& phase, int wave, doubl
 // 14 / 20 / 27 / 40 KB at N = 10 / 15 / 21 / 32 (rounds 1-3: 21 / 27 / 36 / 54 KB).
 __host__ __device__ __forceinline__ int mw_pb_rows(int NW) { return NW == 1 ? 7 : 14; }
 __host__ __device__ __forceinline__ int mw_npass(int Nmax) { return (TOPAY_EP * Nmax + 63) / 64; }
-// [8] partial sums of a workgroup reduction (two phases) | [2 npass] pass totals | [2][NW][64] per-round costs (NW > 1) | [8] masks
+// [8] partial sums of a workgroup reduction (two phases; NW > 1) | [2 npass] pass totals | [2][NW][64] per-round costs
+// (NW > 1) | [NW] masks
+__host__ __device__ __forceinline__ int mw_red_doubles(int NW) { return NW > 1 ? 8 : 0; }
 __host__ __device__ __forceinline__ int mw_misc_doubles(int Nmax, int NW) {
-  return 8 + 2 * mw_npass(Nmax) + (NW > 1 ? 2 * NW * 64 : 0) + 8;
+  return mw_red_doubles(NW) + 2 * mw_npass(Nmax) + (NW > 1 ? 2 * NW * 64 : 0) + NW;
 }
 __host__ __device__ __forceinline__ int lds_doubles_mw(int Nmax, int NW) {
   const int rows = 6 * Nmax;
@@ -297,9 +299,10 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const bool g_early_ok = __builtin_amdgcn_readfirstlane(gate.early_ok ? 1 : 0) != 0;
   int rp = 0;                                  // phase of the workgroup-reduction scratch
   const int npl = __builtin_amdgcn_readfirstlane(C.npass_lds);
-  const lds_dp ptot = c_red + 8;               // [npass][2] pass totals of the XY prefix / chain suffix
-  const lds_dp csr = c_red + 8 + 2 * npl;      // [2][NW][64] pass costs of one round (two rounds in flight; NW > 1 only)
-  TOPAY_LDS unsigned long long* jmask = (TOPAY_LDS unsigned long long*)(c_red + 8 + 2 * npl + (NW > 1 ? 2 * NW * 64 : 0));   // [NW]
+  constexpr int RD = NW > 1 ? 8 : 0;           // (one wave: the reductions need no LDS)
+  const lds_dp ptot = c_red + RD;              // [npass][2] pass totals of the XY prefix / chain suffix
+  const lds_dp csr = c_red + RD + 2 * npl;     // [2][NW][64] pass costs of one round (two rounds in flight; NW > 1 only)
+  TOPAY_LDS unsigned long long* jmask = (TOPAY_LDS unsigned long long*)(c_red + RD + 2 * npl + (NW > 1 ? 2 * NW * 64 : 0));   // [NW]
   constexpr int PBR = NW == 1 ? 7 : 14;        // rows of a wave's pass buffer
   minco_generate_mw<NW, OCC>(C);
 

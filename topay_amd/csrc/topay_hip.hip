@@ -154,7 +154,7 @@ static size_t class_lds_bytes(const ClassDef& cd, int nm) {
       if (q) q++;
     }
   }
-  return (size_t)(d + 8 + 48) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [48]
+  return (size_t)(d + 8 + 40) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [40]
 }
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process

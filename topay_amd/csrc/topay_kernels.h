@@ -46,7 +46,7 @@ __device__ __forceinline__ long long uniform_i64(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [48] solver state parked across an evaluation
+// LDS of one trajectory's workgroup: the evaluation's blocks, then [8] past costs and [40] solver state parked across an evaluation
 template <int NW>
 __host__ __device__ __forceinline__ int eval_lds_doubles(int Nmax_lds) {
   return lds_doubles_mw(Nmax_lds, NW);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   EvalCtx C;
   load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds);  // [8] past costs, then [48] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds);  // [8] past costs, then [40] solver state parked across an evaluation
   const long long no = uniform_i64(Bt.noff[b]);
   const int n = C.n;
   SolveIO S;

@@ -107,7 +107,7 @@ __device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int 
 
 template <int RMAX, int NW = 1, int OCC = 2>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8 + 48] */, int& success_out, double& cost_out, int& interrupted_out) {
+                                                 lds_dp pf /* LDS [8 + 40] */, int& success_out, double& cost_out, int& interrupted_out) {
   const DevParams& P = g_P;
   constexpr int NT = 64 * NW;    // threads of this trajectory's workgroup
   const int tid = C.tid, n = __builtin_amdgcn_readfirstlane(C.n);
