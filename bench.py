@@ -372,8 +372,21 @@ def main():
         o1.reset()
         ok1 = o1.optimize()
         ms1, _ = o1.last_kernel_ms()
-        cfg1 = {"workload": "BASELINE configs[1]: 1 tables scenario x 64 candidates", "solve_ms": float(ms1),
-                "trajectories_per_s": float(len(lens1) / (ms1 * 1e-3)), "success_fraction": float(ok1.mean())}
+        cost1, stats1 = np.nan_to_num(o1.traj_cost.copy()), o1.stats().copy()
+        # the same call on the helper-wave kernels (topay_set_latency_mode 1: a batch of at most one candidate per compute unit
+        # runs on four-wave workgroups whose extra waves join the evaluations only): same bits, shorter solves
+        o1.set_latency_mode(1)
+        o1.reset()
+        o1.optimize()
+        o1.reset()
+        ok1h = o1.optimize()
+        ms1h, _ = o1.last_kernel_ms()
+        cfg1 = {"workload": "BASELINE configs[1]: 1 tables scenario x 64 candidates", "solve_ms": float(ms1h),
+                "trajectories_per_s": float(len(lens1) / (ms1h * 1e-3)), "success_fraction": float(ok1h.mean()),
+                "kernels": "helper waves (topay_set_latency_mode 1), %d of %d launches" % (o1.last_helper_launches(), o1.last_kernel_ms()[1]),
+                "solve_ms_default_kernels": float(ms1),
+                "bit_identical_to_default_kernels": bool((ok1 == ok1h).all() and (cost1 == np.nan_to_num(o1.traj_cost)).all()
+                                                         and (stats1 == o1.stats()).all())}
         o1.close()
         w1.close()
     simd_slots = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count

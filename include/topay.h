@@ -452,6 +452,14 @@ topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */)
  * budgets (alm_max_outer, alm_work_budget, topay_set_groups) the outcome depends on the machine and its load. */
 topay_status topay_optimize_within(topay_ctx* ctx, double budget_ms, int* timed_out);
 
+/* A planning call on an otherwise idle device (BASELINE configs[1]: 64 candidates of one scenario; planner.cpp:930-958 runs its
+ * handful of candidates one after the other).  mode 1: a batch with at most one candidate per compute unit runs its candidates of
+ * up to 32 pieces on workgroups of four waves -- the one-wave solver on the first, all four in every cost / gradient evaluation
+ * (the sample passes of the two sweeps side by side).  Results are those of the default kernels bit for bit (the evaluation is
+ * order-identical for any number of waves, the solver is the one-wave solver); what changes is the time of a solve.  mode 2: for
+ * every batch (tests); mode 0 (the default): never.  Takes effect at the next topay_optimize / topay_optimize_async. */
+topay_status topay_set_latency_mode(topay_ctx* ctx, int mode);
+
 /* ---- multi-GPU: scenarios shard over the GPUs of a node (one process per GPU, nothing of the solve is shared); the one
  * exchange is the all-gather of a 32-byte record per scenario over RCCL (the reference's selection of
  * a scenario's winner, planner.cpp:999-1010, stays local).  A C++ planner shards with these four calls and no torch:
@@ -501,6 +509,8 @@ topay_status topay_gate_timeouts(topay_ctx* ctx, int* n);
 /* Device time (HIP events on the context's stream) of the last topay_optimize / topay_eval_batch
  * solve kernel(s), in milliseconds, and the number of launches it covered. */
 topay_status topay_last_kernel_ms(topay_ctx* ctx, double* ms, int* launches);
+/* How many of those launches ran on the helper-wave kernels (topay_set_latency_mode). */
+topay_status topay_last_helper_launches(topay_ctx* ctx, int* n);
 
 #ifdef __cplusplus
 }

@@ -205,3 +205,88 @@ def test_multiwave_capped_solve_is_bit_identical_to_emulator(cuboids_small):
         res.append((o2.stats(), o2.get_trace(0), o2.get_x(0), o2.getTraj(0)["coeffs"]))
     g, e = res
     assert (g[0] == e[0]).all() and (g[1] == e[1]).all() and (g[2] == e[2]).all() and (g[3] == e[3]).all()
+
+
+def _helper_wave_solves(lib, cs, paths, s1_it, s2_it, outer):
+    """The same capped solves through the default kernels and through the helper-wave kernels (topay_set_latency_mode 2)."""
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    p = api.default_params(api.load(lib))
+    p.s1_lbfgs.max_iterations = s1_it
+    p.s2_lbfgs.max_iterations = s2_it
+    p.alm_max_outer = outer
+    res = []
+    for mode in (0, 2):
+        opt = api.MomaTrajOptBatch(params=p, device=0, lib_path=lib)
+        set_map(opt, cs["world"])
+        opt.set_init_traj(lens, np.concatenate(paths))
+        opt.set_latency_mode(mode)
+        opt.set_trace(64)
+        ok = opt.optimize()
+        assert (opt.last_helper_launches() > 0) == (mode == 2)
+        res.append(dict(ok=ok, st=opt.stats(), alm=opt.alm_state(), cost=opt.traj_cost.copy(),
+                        x=[opt.get_x(b) for b in range(len(paths))], tr=[opt.get_trace(b) for b in range(len(paths))],
+                        co=[opt.getTraj(b)["coeffs"] for b in range(len(paths)) if ok[b]], N=opt.n_pieces()))
+    a, h = res
+    assert (a["ok"] == h["ok"]).all() and (a["st"] == h["st"]).all() and (a["alm"] == h["alm"]).all()
+    assert (np.nan_to_num(a["cost"]) == np.nan_to_num(h["cost"])).all()
+    for b in range(len(paths)):
+        assert (a["x"][b] == h["x"][b]).all() and (a["tr"][b] == h["tr"][b]).all(), (b, int(a["N"][b]))
+    for ca, ch in zip(a["co"], h["co"]):
+        assert (ca == ch).all()
+    return a["N"]
+
+
+def test_helper_wave_kernels_solve_to_the_same_bits_on_cpu(cuboids_small):
+    """topay_set_latency_mode: four-wave workgroups whose extra waves only join the evaluations.  Candidates of every one-wave
+    class (4..11, 14, 19 and 26 pieces; the 33-piece one stays on its own four-wave kernel) through capped solves in the lane
+    emulator: every evaluated cost, the counters, the iterate, the ALM state and the coefficients equal the default kernels'."""
+    cs = cuboids_small
+    paths = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in range(len(cs["lens"]))] + [serpentine_path(L) for L in (14.0, 19.5, 27.0, 34.0)]
+    N = _helper_wave_solves(EMU_LIB, cs, paths, 4, 3, 1)
+    assert N.max() >= 33 and (N[6:9] > np.array([10, 15, 21])).all() and (N[6:9] <= np.array([15, 21, 32])).all(), N
+
+
+@pytest.mark.gpu
+def test_helper_wave_kernels_solve_to_the_same_bits_on_gpu(cuboids_small):
+    """The same on the MI355X, to convergence (uncapped): the six candidates of the small fixture + one per one-wave class."""
+    cs = cuboids_small
+    paths = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in range(len(cs["lens"]))] + [serpentine_path(L) for L in (14.0, 19.5, 27.0, 34.0)]
+    lens = np.array([len(p) for p in paths], dtype=np.int32)
+    res = []
+    for mode in (0, 1):
+        opt = api.MomaTrajOptBatch(device=0)
+        set_map(opt, cs["world"])
+        opt.set_init_traj(lens, np.concatenate(paths))
+        opt.set_latency_mode(mode)      # mode 1: this batch is small enough
+        ok = opt.optimize()
+        assert (opt.last_helper_launches() > 0) == (mode == 1)
+        res.append((ok, opt.stats(), np.nan_to_num(opt.traj_cost), [opt.get_x(b) for b in range(len(paths))], opt.last_kernel_ms()[0]))
+    a, h = res
+    assert (a[0] == h[0]).all() and (a[1] == h[1]).all() and (a[2] == h[2]).all()
+    for xa, xh in zip(a[3], h[3]):
+        assert (xa == xh).all()
+    print("solve of %d candidates: %.1f ms on the default kernels, %.1f ms with helper waves" % (len(paths), a[4], h[4]))
+
+
+def test_rare_rows_of_a_piece_that_straddles_two_passes_keep_the_one_wave_order(cuboids_small):
+    """Regression (round 4): the 637th evaluation of the 26-piece serpentine's solve -- joint velocity / acceleration rows
+    flagged in a pass whose last piece continues in the next pass of the same round.  The several-waves gradient phase added a
+    round's order-0 joint rows first and its rare rows afterwards; the one-wave phase does both pass by pass, so the two
+    disagreed by 1.5e-10 in such a piece's joint rows (found by the helper-wave kernels, whose solves must reproduce the
+    one-wave kernels' bit for bit).  tests/golden/order_identity_n26.npz: that decision vector and ALM state."""
+    import os
+    cs = cuboids_small
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "order_identity_n26.npz"))
+    path = serpentine_path(27.0)
+    emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(emu, cs["world"])
+    emu.set_init_traj(np.array([len(path)], dtype=np.int32), path)
+    assert int(emu.n_pieces()[0]) == 26 and len(fx["x"]) == 10 * 26 - 8
+    r = {w: emu.eval(int(fx["stage"]), 0, fx["x"], fx["lam"], fx["rho"], waves=w) for w in (1, 2, 4)}
+    for w in (2, 4):
+        assert r[w][0] == r[1][0] and (r[w][1] == r[1][1]).all() and (r[w][2] == r[1][2]).all(), w
+    o = orc.Oracle(cs["map"])
+    o.set_init_traj(path)
+    o.set_alm(fx["lam"], fx["rho"])
+    f, g = o.eval(int(fx["stage"]), fx["x"])
+    assert abs(f - r[1][0]) <= 1e-11 * abs(f) and np.abs(g - r[1][1]).max() <= 1e-10 * np.abs(g).max()

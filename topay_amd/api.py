@@ -146,6 +146,8 @@ def load(path=None):
     L.topay_gate_timeouts.argtypes = [C.c_void_p, c_ip]
     L.topay_class_of.argtypes = [C.c_int, c_ip, c_ip, c_ip]
     L.topay_set_groups.argtypes = [C.c_void_p, c_ip, C.c_int]
+    if hasattr(L, "topay_set_latency_mode"):   # (older builds of the library under tools/libs, A/B runs)
+        L.topay_set_latency_mode.argtypes = [C.c_void_p, C.c_int]
     L.topay_comm_unique_id.argtypes = [C.POINTER(CommId)]
     L.topay_comm_init.argtypes = [C.c_void_p, C.POINTER(CommId), C.c_int, C.c_int]
     L.topay_comm_destroy.argtypes = [C.c_void_p]
@@ -159,6 +161,8 @@ def load(path=None):
     L.topay_get_nmax.argtypes = [C.c_void_p, c_ip, c_ip]
     L.topay_check_feasible.argtypes = [C.c_void_p, c_ip]
     L.topay_last_kernel_ms.argtypes = [C.c_void_p, c_dp, c_ip]
+    if hasattr(L, "topay_last_helper_launches"):
+        L.topay_last_helper_launches.argtypes = [C.c_void_p, c_ip]
     L.topay_test_math.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
     L.topay_set_trace.argtypes = [C.c_void_p, C.c_int]
     L.topay_get_trace.argtypes = [C.c_void_p, C.c_int, c_dp]
@@ -700,6 +704,11 @@ class MomaTrajOptBatch:
         g = None if group_id is None else np.ascontiguousarray(group_id, dtype=np.int32)
         _chk(self.L, self.L.topay_set_groups(self.h, _ip(g), int(cancel_budget) if g is not None else 0))
 
+    def set_latency_mode(self, mode):
+        """0: never (default); 1: batches with at most one candidate per compute unit run on four-wave workgroups whose extra
+        waves join the evaluations only (same bits, shorter solves); 2: every batch."""
+        _chk(self.L, self.L.topay_set_latency_mode(self.h, int(mode)))
+
     def cancel(self):
         _chk(self.L, self.L.topay_cancel(self.h))
 
@@ -827,6 +836,11 @@ class MomaTrajOptBatch:
         out = np.zeros(4 * len(a))
         _chk(self.L, self.L.topay_test_math(self.h, len(a), _dp(a), _dp(b), _dp(out)))
         return out.reshape(-1, 4)
+
+    def last_helper_launches(self):
+        n = C.c_int(0)
+        _chk(self.L, self.L.topay_last_helper_launches(self.h, C.byref(n)))
+        return n.value
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

@@ -722,117 +722,118 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       if (lane == 0) jmask[wave] = mk;
     }
     wg_barrier<NW>();
-    // row accumulation: the samples of the row's piece in ascending order, pass by pass (the one-wave order)
+    // row accumulation of one pass of the round into the accumulators of row slot r
+    auto accumulate = [&](int r, int q) __attribute__((always_inline)) {
+      const int p2 = k * NW + q;
+      const int pi = rpiece[r];
+      const double h0 = rbh[r][0], h1 = rbh[r][1], h2 = rbh[r][2];
+      const int k0 = rk[r], k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
+      const int e_lo = max(TOPAY_EP * pi, p2 * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, p2 * 64 + 64), NE);
+      if (e_lo >= e_hi) return;
+      lds_cdp pq = pball + q * (PBR * 64);
+      double gt = 0.0;
+      constexpr int CH = 3;
+      for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
+        double pb[CH][NV], t0[CH], t1[CH], t2[CH];
 #pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-      if (ract[r]) {
-        const int pi = rpiece[r];
-        const double h0 = rbh[r][0], h1 = rbh[r][1], h2 = rbh[r][2];
-        const int k0 = rk[r], k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
-        for (int q = 0; q < NW; q++) {
-          const int p2 = k * NW + q;
-          const int e_lo = max(TOPAY_EP * pi, p2 * 64), e_hi = min(min(TOPAY_EP * pi + TOPAY_EP, p2 * 64 + 64), NE);
-          if (e_lo >= e_hi) continue;
-          lds_cdp pq = pball + q * (PBR * 64);
-          double gt = 0.0;
-          constexpr int CH = 3;
-          for (int c0 = e_lo; c0 < e_hi; c0 += CH) {
-            double pb[CH][NV], t0[CH], t1[CH], t2[CH];
+        for (int u = 0; u < CH; u++) {
+          const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
+          const int l = ee - p2 * 64, mm = ee - TOPAY_EP * pi;
+          lds_cdp pj = c_pw + 12 * mm;
+          t0[u] = pj[k0]; t1[u] = pj[k1]; t2[u] = pj[k2];
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-              const int ee = (c0 + u < e_hi) ? c0 + u : e_hi - 1;
-              const int l = ee - p2 * 64, mm = ee - TOPAY_EP * pi;
-              lds_cdp pj = c_pw + 12 * mm;
-              t0[u] = pj[k0]; t1[u] = pj[k1]; t2[u] = pj[k2];
+          for (int v = 0; v < NV; v++) pb[u][v] = pq[v * 64 + l];
+        }
 #pragma unroll
-              for (int v = 0; v < NV; v++) pb[u][v] = pq[v * 64 + l];
-            }
+        for (int u = 0; u < CH; u++) {
+          const bool ok = c0 + u < e_hi;
+          const double b0 = h0 * t0[u], b1 = h1 * t1[u], b2 = h2 * t2[u];
+          const double i0 = fma(b2, pb[u][2], fma(b1, pb[u][1], b0 * pb[u][0]));
+          const double i1 = fma(b2, pb[u][4], b1 * pb[u][3]);
+          a0[r] += ok ? i0 : 0.0;
+          a1[r] += ok ? i1 : 0.0;
+          gt += ok ? pb[u][5] : 0.0;
+          if (STAGE == 2) {
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-              const bool ok = c0 + u < e_hi;
-              const double b0 = h0 * t0[u], b1 = h1 * t1[u], b2 = h2 * t2[u];
-              const double i0 = fma(b2, pb[u][2], fma(b1, pb[u][1], b0 * pb[u][0]));
-              const double i1 = fma(b2, pb[u][4], b1 * pb[u][3]);
-              a0[r] += ok ? i0 : 0.0;
-              a1[r] += ok ? i1 : 0.0;
-              gt += ok ? pb[u][5] : 0.0;
-              if (STAGE == 2) {
-#pragma unroll
-                for (int qq = 0; qq < 7; qq++) {
-                  const double nq = fma(b0, pb[u][6 + qq], aq[r][qq]);
-                  aq[r][qq] = ok ? nq : aq[r][qq];
-                }
-              }
+            for (int qq = 0; qq < 7; qq++) {
+              const double nq = fma(b0, pb[u][6 + qq], aq[r][qq]);
+              aq[r][qq] = ok ? nq : aq[r][qq];
             }
           }
-          if (rk[r] == 0) c_gdT[pi] += gt;
         }
       }
-    }
+      if (rk[r] == 0) c_gdT[pi] += gt;
+    };
+    unsigned long long any = 0;
     if (STAGE == 2) {
-      // rare: joint velocity / acceleration gradBeta rows 1 and 2 (moma_traj_opt.cpp:1689, 1703) of the flagged samples,
-      // visited in ascending sample order by every row thread of their piece
-      unsigned long long any = 0;
 #pragma unroll
       for (int q = 0; q < NW; q++) any |= jmask[q];
-      if (any != 0) {
-        double g1[7], g2[7];
+    }
+    if (any == 0) {
+      // the samples of the row's piece in ascending order, pass by pass (the one-wave order)
 #pragma unroll
-        for (int q = 0; q < 7; q++) { g1[q] = 0.0; g2[q] = 0.0; }
-        if (jva) {
+      for (int r = 0; r < RMAX; r++) {
+        if (ract[r]) {
+          for (int q = 0; q < NW; q++) accumulate(r, q);
+        }
+      }
+    } else {
+      // rare: joint velocity / acceleration gradBeta rows 1 and 2 (moma_traj_opt.cpp:1689, 1703) of flagged samples.  Within a
+      // pass the order-0 rows of all its samples first, then the rare rows of its flagged samples, pass by pass -- the
+      // one-wave order exactly, also for a piece whose samples straddle two passes of this round.
+      for (int q = 0; q < NW; q++) {
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+          if (ract[r]) accumulate(r, q);
+        }
+        unsigned long long todo = jmask[q];   // (the same for every thread: the barriers below are uniform)
+        if (todo == 0) continue;
+        wg_barrier<NW>();   // every row thread is done with this pass's buffer
+        if (wave == q && jva) {
           Basis B;
           make_basis(j * half, B);
           const double omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
 #pragma unroll
-          for (int q = 0; q < 7; q++) {
-            double p0, p1, p2;
-            poly3(cL, rows, i, 2 + q, B, p0, p1, p2);
-            const double vDq = p1 * p1 - P.joint_vel_limit2[q];
-            const double vD2q = p2 * p2 - P.joint_acc_limit2[q];
+          for (int qq = 0; qq < 7; qq++) {
+            double p0, p1, p2, g1 = 0.0, g2 = 0.0;
+            poly3(cL, rows, i, 2 + qq, B, p0, p1, p2);
+            const double vDq = p1 * p1 - P.joint_vel_limit2[qq];
+            const double vD2q = p2 * p2 - P.joint_acc_limit2[qq];
             if (vDq > 0) {
               double pe, pd;
               smoothL1(vDq, P.relu_mu, pe, pd);
-              g1[q] = omg * step * P.s2_mani_vel_weight * pd * 2.0 * p1;
+              g1 = omg * step * P.s2_mani_vel_weight * pd * 2.0 * p1;
             }
             if (vD2q > 0) {
               double pe, pd;
               smoothL1(vD2q, P.relu_mu, pe, pd);
-              g2[q] = omg * step * P.s2_mani_acc_weight * pd * 2.0 * p2;
+              g2 = omg * step * P.s2_mani_acc_weight * pd * 2.0 * p2;
             }
-          }
-        }
-        wg_barrier<NW>();   // every row thread is done with the pass buffers
-        if (jva) {
-#pragma unroll
-          for (int q = 0; q < 7; q++) {
-            pbuf[q * 64 + lane] = g1[q];
-            pbuf[(7 + q) * 64 + lane] = g2[q];
+            pbuf[qq * 64 + lane] = g1;
+            pbuf[(7 + qq) * 64 + lane] = g2;
           }
         }
         wg_barrier<NW>();
-        for (int q2 = 0; q2 < NW; q2++) {
-          unsigned long long todo = jmask[q2];
-          lds_cdp pq = pball + q2 * (PBR * 64);
-          while (todo) {
-            const int src = __ffsll(todo) - 1;
-            todo &= todo - 1;
-            const int se = (k * NW + q2) * 64 + src;
-            const int spi = se / TOPAY_EP, smm = se - TOPAY_EP * spi;
-            double b1v[7], b2v[7];
+        lds_cdp pq = pball + q * (PBR * 64);
+        while (todo) {
+          const int src = __ffsll(todo) - 1;
+          todo &= todo - 1;
+          const int se = (k * NW + q) * 64 + src;
+          const int spi = se / TOPAY_EP, smm = se - TOPAY_EP * spi;
+          double b1v[7], b2v[7];
 #pragma unroll
-            for (int q = 0; q < 7; q++) { b1v[q] = pq[q * 64 + src]; b2v[q] = pq[(7 + q) * 64 + src]; }
+          for (int qq = 0; qq < 7; qq++) { b1v[qq] = pq[qq * 64 + src]; b2v[qq] = pq[(7 + qq) * 64 + src]; }
 #pragma unroll
-            for (int r = 0; r < RMAX; r++) {
-              if (ract[r] && rpiece[r] == spi) {
-                const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
-                const double b1 = rbh[r][1] * c_pw[12 * smm + k1], b2 = rbh[r][2] * c_pw[12 * smm + k2];
+          for (int r = 0; r < RMAX; r++) {
+            if (ract[r] && rpiece[r] == spi) {
+              const int k1 = rk[r] >= 1 ? rk[r] - 1 : 0, k2 = rk[r] >= 2 ? rk[r] - 2 : 0;
+              const double b1 = rbh[r][1] * c_pw[12 * smm + k1], b2 = rbh[r][2] * c_pw[12 * smm + k2];
 #pragma unroll
-                for (int q = 0; q < 7; q++) {
-                  double a = aq[r][q];
-                  a = fma(b1, b1v[q], a);
-                  a = fma(b2, b2v[q], a);
-                  aq[r][q] = a;
-                }
+              for (int qq = 0; qq < 7; qq++) {
+                double a = aq[r][qq];
+                a = fma(b1, b1v[qq], a);
+                a = fma(b2, b2v[qq], a);
+                aq[r][qq] = a;
               }
             }
           }

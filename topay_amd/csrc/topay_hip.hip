@@ -117,11 +117,14 @@ struct ClassDef {
   solve_kernel_t solve;
   eval_kernel_t eval;
   int occ = 2;   // waves per SIMD the kernel is built for (512 / occ registers per lane; every kernel: 256, no AGPRs)
+  solve_kernel_t lat = nullptr;   // helper-wave kernel of a one-wave class (topay_set_latency_mode): 4 waves per workgroup
 };
+static const int kLatWaves = 4;
 static const ClassDef* class_table() {
   static const ClassDef* tab = [] {
     static ClassDef t[TOPAY_NBUCKET] = {
-        {10, 1, 1, k_solve1, k_eval1, 2}, {15, 2, 1, k_solve2, k_eval2, 2}, {21, 2, 1, k_solve2, k_eval2, 2}, {32, 3, 1, k_solve3, k_eval3, 2},
+        {10, 1, 1, k_solve1, k_eval1, 2, k_lat1}, {15, 2, 1, k_solve2, k_eval2, 2, k_lat2}, {21, 2, 1, k_solve2, k_eval2, 2, k_lat2},
+        {32, 3, 1, k_solve3, k_eval3, 2, k_lat3},
         {42, 2, 4, k_solve2w4, k_eval2w4, 2}, {64, 2, 4, k_solve2w4, k_eval2w4, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2}};
     // Four waves per trajectory for N = 33..64 since round 4.  Round 3 (one wave per SIMD), one / two / four waves for both
     // classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 / 1.03 s -- four waves halve a long
@@ -212,6 +215,7 @@ struct topay_ctx {
   int n_gate = 0;            // ... of which the dispatch gate waits for (the classes of up to 32 pieces)
   bool gate = true;
   bool gate_in_solve = true;   // feasibility gate by the solving wave (TOPAY_GATE_IN_SOLVE=0: the separate kernel only)
+  int latency_mode = 0;        // topay_set_latency_mode: 0 never, 1 batches of at most one candidate per compute unit, 2 always
   bool gate_done = false;      // the resident flags / report are those of the last solve
   // cancellation: planning call of every candidate, the window after a call's first feasible success (piece-evaluations)
   std::vector<int> h_group;
@@ -240,7 +244,7 @@ struct topay_ctx {
   DevBatch db;
   bool have_traj = false, solved = false;
   double last_ms = 0.0;
-  int last_launches = 0;
+  int last_launches = 0, last_helper_launches = 0;
 };
 
 static void make_dev_params(const topay_params_t& p, DevParams& d) {
@@ -1157,6 +1161,7 @@ static hipError_t set_kernel_attributes(int device) {
     for (int k = 0; k < TOPAY_NBUCKET && e == hipSuccess; k++) {
       e = hipFuncSetAttribute((const void*)ct[k].solve, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ct[k].eval, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess && ct[k].lat) e = hipFuncSetAttribute((const void*)ct[k].lat, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     g_attr_err[device % 16] = e;
   });
@@ -1180,7 +1185,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
   // Longest jobs first.  The context's main stream waits for all of them (events), so the caller's
   // ev0/ev1 pair on the main stream brackets the whole solve.
   const ClassDef* ct = class_table();
-  int launches = 0, off = 0;
+  int launches = 0, helper_launches = 0, off = 0;
   topay_status ps = push_params(c);
   if (ps != TOPAY_OK) return ps;
   HIPCHK(set_kernel_attributes(c->device));
@@ -1229,12 +1234,20 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
       grid = pgrid[k];
     }
     off += nk;
-    const size_t lds = class_lds_bytes(ct[k], nm);
+    // helper-wave kernels (topay_set_latency_mode): a one-wave class of a small batch runs on four-wave workgroups whose
+    // extra waves only join the evaluations -- same bits, shorter sample sweeps
+    const bool lat = !EVAL && ct[k].lat && (c->latency_mode == 2 || (c->latency_mode == 1 && c->B <= c->simd_slots / 4));
+    size_t lds = class_lds_bytes(ct[k], nm);
+    if (lat) {
+      lds = (size_t)(lds_doubles_mw(nm, kLatWaves) + 8 + 40 + TOPAY_CMD_DOUBLES) * sizeof(double);
+      grid = nk;   // a workgroup per candidate of the class (at most one per compute unit in mode 1)
+    }
     if (k == topay_ctx::NBUCKET - 2 && !c->cls[topay_ctx::NBUCKET - 1].empty() && c->bstream[k] == c->stream)
       HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));   // both long classes in one batch: they must not serialise
     hipStream_t st = c->bstream[k];
     if (st != c->stream) HIPCHK(hipStreamWaitEvent(st, c->bstart, 0));
     if constexpr (EVAL) hipLaunchKernelGGL(ct[k].eval, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, args..., nm);
+    else if (lat) { hipLaunchKernelGGL(ct[k].lat, dim3(grid), dim3(64 * kLatWaves), lds, st, d, (const DevMap*)c->dmaps.p, nm); helper_launches++; }
     else hipLaunchKernelGGL(ct[k].solve, dim3(grid), dim3(64 * ct[k].nw), lds, st, d, (const DevMap*)c->dmaps.p, nm);
     HIPCHK(hipGetLastError());
     if (st != c->stream) HIPCHK(hipEventRecord(c->bevent[k], st));
@@ -1243,6 +1256,7 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
   for (int k = 0; k < topay_ctx::NBUCKET; k++)
     if (!c->cls[k].empty() && c->bstream[k] != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->bevent[k], 0));
   c->last_launches = launches;
+  c->last_helper_launches = helper_launches;
   return TOPAY_OK;
 }
 
@@ -1445,6 +1459,13 @@ topay_status topay_set_groups(topay_ctx* c, const int* group_id, int cancel_budg
   // short candidates of their planning call -- the ones that succeed first on the work clock -- have already run.  The
   // outcome does not depend on the order (the rule is applied to the candidates' own clocks), only the time saved does.
   return upload_order(c, true);
+}
+
+// Helper-wave kernels for small batches (include/topay.h)
+topay_status topay_set_latency_mode(topay_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return TOPAY_ERR_INVALID_ARG;
+  c->latency_mode = mode;
+  return TOPAY_OK;
 }
 
 // threads.interrupt_all() for the solve in flight (planner.cpp:952): every candidate stops at its next interruption
@@ -2456,6 +2477,12 @@ topay_status topay_last_kernel_ms(topay_ctx* c, double* ms, int* launches) {
   if (!c) return TOPAY_ERR_INVALID_ARG;
   if (ms) *ms = c->last_ms;
   if (launches) *launches = c->last_launches;
+  return TOPAY_OK;
+}
+
+topay_status topay_last_helper_launches(topay_ctx* c, int* n) {
+  if (!c || !n) return TOPAY_ERR_INVALID_ARG;
+  *n = c->last_helper_launches;
   return TOPAY_OK;
 }
 

@@ -145,9 +145,11 @@ __device__ __forceinline__ void eval_body(const DevBatch& Bt, const DevMap* maps
 template <int OCC>
 __device__ __noinline__ void feasibility_gate_in_solve(const FeasIO F, const TOPAY_GLB DevMap* mp) { feasibility_gate(F, mp); }
 
-template <int RMAX, int NW, int OCC>
+// NWE = waves of the workgroup (= waves of an evaluation), NW = waves the solver runs on: NWE > NW = 1 is the helper-wave
+// scheme of the k_lat* kernels (topay_solve.h).
+template <int RMAX, int NW, int OCC, int NWE = NW, int RMAX_E = RMAX>
 __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps, int Nmax_lds, int b) {
-  constexpr int NT = 64 * NW;
+  constexpr int NT = 64 * NWE;
   const unsigned long long t_begin = wall_clock64();
   // scheduling only (never read by the solve): lets the host issue the next batch once every candidate of this one
   // is resident, see topay_optimize_async
@@ -159,9 +161,9 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 #endif
   }
   EvalCtx C;
-  load_ctx<RMAX, NW>(C, Bt, b, Nmax_lds);
+  load_ctx<RMAX_E, NWE>(C, Bt, b, Nmax_lds);
   const TOPAY_GLB DevMap* mp = (const TOPAY_GLB DevMap*)(maps + __builtin_amdgcn_readfirstlane(Bt.map_id[b]));
-  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NW>(Nmax_lds);  // [8] past costs, then [40] solver state parked across an evaluation
+  lds_dp pf = TOPAY_LDS_PTR + eval_lds_doubles<NWE>(Nmax_lds);  // [8] past costs, then [40] solver state parked across an evaluation (+ the command block of the helper-wave kernels)
   const long long no = uniform_i64(Bt.noff[b]);
   const int n = C.n;
   SolveIO S;
@@ -189,10 +191,18 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
   }
   int success = 0, interrupted = 0;
   double cost = 0.0;
-  solve_trajectory<RMAX, NW, OCC>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
+  if constexpr (NWE != NW) {
+    C.x = S.x;
+    C.g = S.g;
+    __syncthreads();   // x0 is in place for wave 0
+    if (C.wave == 0) solve_trajectory<RMAX, NW, OCC, NWE, RMAX_E>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
+    else eval_helper_loop<RMAX_E, NWE, OCC>(C, mp, pf + 48);
+  } else {
+    solve_trajectory<RMAX, NW, OCC>(C, mp, S, Bt.s1_past[b], pf, success, cost, interrupted);
+  }
   // results: state of the last evaluation (getTraj(), moma_traj_opt.h:943-946) + traj_cost
   __syncthreads();
-  store_result<NW>(C, Bt, b);
+  store_result<NWE>(C, Bt, b);
   if (Bt.gate_in_solve) {
     // printConstraintsSituations of the returned trajectory (planner.cpp:878-880) by wave 0, from the result blocks just
     // written; panels and sample times go to the candidate's L-BFGS history blocks, which are dead now
@@ -252,7 +262,7 @@ __device__ __forceinline__ void solve_one(const DevBatch& Bt, const DevMap* maps
 // The queues of one batch, own class first, then the smaller ones (see DevBatch::queue_next).  Without queues
 // (queue_next null: one workgroup per position of `order`) the loop body runs once, for order[blockIdx.x]: one call site
 // of the solve for both launch schemes, i.e. one copy of the solver in the kernel.
-template <int RMAX, int NW, int OCC>
+template <int RMAX, int NW, int OCC, int NWE = NW, int RMAX_E = RMAX>
 __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* maps, int Nmax_lds, int my_class) {
   const bool queued = B.queue_next != nullptr;
   const int lowest = queued ? B.queue_lowest : my_class;
@@ -262,7 +272,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
       int pos = 0;
       if (queued) {
         if (threadIdx.x == 0) pos = atomicAdd(B.queue_next + cls, 1);
-        if (NW == 1) {
+        if (NWE == 1) {
           pos = __shfl(pos, 0);
         } else {   // the position travels to the other waves through the first LDS word (nothing of a solve is live here)
           TOPAY_LDS int* w0 = (TOPAY_LDS int*)TOPAY_LDS_PTR;
@@ -275,7 +285,7 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
         pos = once;
       }
       if (pos >= count) break;
-      solve_one<RMAX, NW, OCC>(B, maps, Nmax_lds, B.order[off + pos]);
+      solve_one<RMAX, NW, OCC, NWE, RMAX_E>(B, maps, Nmax_lds, B.order[off + pos]);
       __syncthreads();
     }
   }
@@ -288,9 +298,9 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
 // length); a resident workgroup that fetches its next candidate itself leaves no slot idle and starts candidates
 // strictly in queue order.  Which workgroup solves which candidate is timing-dependent, the result of a candidate is
 // not (nothing is shared between candidates).
-template <int RMAX, int NW, int OCC>
+template <int RMAX, int NW, int OCC, int NWE = NW, int RMAX_E = RMAX>
 __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* maps, int Nmax_lds) {
-  drain_queues<RMAX, NW, OCC>(Bt, maps, Nmax_lds, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
+  drain_queues<RMAX, NW, OCC, NWE, RMAX_E>(Bt, maps, Nmax_lds, Bt.queue_class);   // the batch is the kernel argument (scalar loads, no copy)
 }
 
 // One wave per trajectory: k_solve<rows per lane> for N <= 10 / 21 / 32, built for two waves per SIMD (256 registers, no
@@ -300,6 +310,12 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 #define TOPAY_SOLVE_KERNEL(NAME, R, W, OCC)                                                                         \
   __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds) { \
     solve_body<R, W, OCC>(Bt, maps, Nmax_lds);                                                             \
+  }
+// Helper-wave kernels for a handful of candidates (a planning call on an otherwise idle device): the one-wave solver of
+// rows-per-lane RS on wave 0, evaluations on WE waves with RE rows per thread.  Results are those of k_solve<RS>, bit for bit.
+#define TOPAY_LATENCY_KERNEL(NAME, RS, RE, WE, OCC)                                                        \
+  __global__ void __launch_bounds__(64 * WE, OCC) NAME(DevBatch Bt, const DevMap* maps, int Nmax_lds) {    \
+    solve_body<RS, 1, OCC, WE, RE>(Bt, maps, Nmax_lds);                                                    \
   }
 #define TOPAY_EVAL_KERNEL(NAME, R, W, OCC)                                                                          \
   __global__ void __launch_bounds__(64 * W, OCC) NAME(DevBatch Bt, const DevMap* maps, int stage, int repeats, int Nmax_lds) { \
@@ -311,6 +327,9 @@ TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
 TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, 2)
+TOPAY_LATENCY_KERNEL(k_lat1, 1, 1, 4, 2)
+TOPAY_LATENCY_KERNEL(k_lat2, 2, 1, 4, 2)
+TOPAY_LATENCY_KERNEL(k_lat3, 3, 1, 4, 2)
 TOPAY_EVAL_KERNEL(k_eval1, 1, 1, 2)
 TOPAY_EVAL_KERNEL(k_eval2, 2, 1, 2)
 TOPAY_EVAL_KERNEL(k_eval3, 3, 1, 2)

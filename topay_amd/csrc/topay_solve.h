@@ -105,11 +105,45 @@ __device__ __forceinline__ double vec_dot_part(glb_cdp a, glb_cdp b, int n, int 
   return s;
 }
 
-template <int RMAX, int NW = 1, int OCC = 2>
+// Helper waves (the kernels for a handful of candidates, topay_kernels.h: k_lat*).  With NWE > NW = 1 the workgroup has NWE
+// waves but the solver runs on wave 0 alone -- its vectors, reductions and two-loop recursion are those of the one-wave
+// kernels, so the bits of a solve are the one-wave bits -- and the other waves only join the evaluations (which are
+// order-identical for any number of waves, topay_eval_mw.h): wave 0 posts the evaluation's inputs in a command block in
+// LDS, every wave meets at a workgroup barrier and evaluates.  What that shortens is the sample passes of the two sweeps (a
+// 10-piece candidate has three; four waves run them side by side); the solver's serial chains stay.
+//   command block, 16 doubles: finit, thr, early, skip_thr, lam0, lam1, rho0, rho1 | ints: op (1 evaluate, 0 leave), stage,
+//   gate.always, gate.has_early, gate.early_ok
+#define TOPAY_CMD_DOUBLES 16
+template <int RMAX_E, int NWE, int OCC>
+__device__ __forceinline__ void eval_helper_loop(EvalCtx& C, const TOPAY_GLB DevMap* mp, lds_dp cmd) {
+  for (;;) {
+    __syncthreads();
+    const TOPAY_LDS int* ic = (const TOPAY_LDS int*)(cmd + 8);
+    if (__builtin_amdgcn_readfirstlane(ic[0]) == 0) break;
+    GradGate gate;
+    gate.finit = cmd[0]; gate.thr = cmd[1]; gate.early = cmd[2]; gate.skip_thr = cmd[3];
+    C.lam0 = cmd[4]; C.lam1 = cmd[5]; C.rho0 = cmd[6]; C.rho1 = cmd[7];
+    const int stage = __builtin_amdgcn_readfirstlane(ic[1]);
+    gate.always = ic[2] != 0; gate.has_early = ic[3] != 0; gate.early_ok = ic[4] != 0;
+    if (stage == 1) (void)eval_cost_grad_mw<1, RMAX_E, NWE, OCC>(C, mp, gate);
+    else (void)eval_cost_grad_mw<2, RMAX_E, NWE, OCC>(C, mp, gate);
+    wg_lds_barrier();
+  }
+}
+
+template <int RMAX, int NW = 1, int OCC = 2, int NWE = NW, int RMAX_E = RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
-                                                 lds_dp pf /* LDS [8 + 40] */, int& success_out, double& cost_out, int& interrupted_out) {
+                                                 lds_dp pf /* LDS [8 + 40], then the command block if NWE != NW */, int& success_out,
+                                                 double& cost_out, int& interrupted_out) {
+  static_assert(NWE == NW || NW == 1, "helper waves join a one-wave solver");
+  constexpr bool HELPERS = NWE != NW;
   const DevParams& P = g_P;
-  constexpr int NT = 64 * NW;    // threads of this trajectory's workgroup
+  constexpr int NT = 64 * NW;    // threads that run the solver
+  // barrier among the solver's threads (with helper waves: wave 0 alone -- no workgroup barrier outside the hand-shake)
+  auto ssync = [&]() {
+    if constexpr (HELPERS) { wave_global_sync(); lds_sync(); }
+    else __syncthreads();
+  };
   const int tid = C.tid, n = __builtin_amdgcn_readfirstlane(C.n);
   constexpr int EPL = 2 * RMAX;  // decision-vector elements per thread: n <= NT * EPL
   // sums / maxima over the trajectory's threads in a fixed order: the wave tree, then (NW > 1) the waves' partial results
@@ -179,7 +213,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
     // ------------------------------------------------------------------ evaluate at x
-    __syncthreads();
+    ssync();
     STAMP(C, 9);  // L-BFGS bookkeeping between evaluations
     double f;
     GradGate gate;
@@ -217,9 +251,17 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       qk[9] = (unsigned long long)S.stats; qk[10] = (unsigned long long)S.trace; qk[11] = (unsigned long long)mp;
       qk[12] = (unsigned long long)S.grp_tau; qk[13] = (unsigned long long)S.cancel_flag;
     }
-    if (stage == 1) f = eval_cost_grad_mw<1, RMAX, NW, OCC>(C, mp, gate);
-    else f = eval_cost_grad_mw<2, RMAX, NW, OCC>(C, mp, gate);
-    if (NW > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
+    if constexpr (HELPERS) {
+      lds_dp cmd = pf + 48;
+      cmd[0] = gate.finit; cmd[1] = gate.thr; cmd[2] = gate.early; cmd[3] = gate.skip_thr;
+      cmd[4] = C.lam0; cmd[5] = C.lam1; cmd[6] = C.rho0; cmd[7] = C.rho1;
+      TOPAY_LDS int* ic = (TOPAY_LDS int*)(cmd + 8);
+      ic[0] = 1; ic[1] = stage; ic[2] = gate.always ? 1 : 0; ic[3] = gate.has_early ? 1 : 0; ic[4] = gate.early_ok ? 1 : 0;
+      __syncthreads();   // the helper waves wait here (eval_helper_loop); x written above is visible to them
+    }
+    if (stage == 1) f = eval_cost_grad_mw<1, RMAX_E, NWE, OCC>(C, mp, gate);
+    else f = eval_cost_grad_mw<2, RMAX_E, NWE, OCC>(C, mp, gate);
+    if (NWE > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
     rp = 0;
     {
       // (read back as wave-uniform values: scalar registers, scalar branches, scalar base addresses for the vector loads)
@@ -370,9 +412,9 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             if (rate < lp.delta) { ret = TOPAY_LBFGS_STOP; fin = true; }
           }
           if (!fin) {
-            __syncthreads();
+            ssync();
             if (tid == 0) pf[k % past] = fx;
-            __syncthreads();
+            ssync();
           }
         }
         if (!fin && lp.max_iterations != 0 && lp.max_iterations <= k) { ret = TOPAY_LBFGSERR_MAXIMUMITERATION; fin = true; }
@@ -582,6 +624,11 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       evals = 0;
       mode = MODE_INIT;
     }
+  }
+  if constexpr (HELPERS) {   // release the helper waves
+    TOPAY_LDS int* ic = (TOPAY_LDS int*)(pf + 48 + 8);
+    ic[0] = 0;
+    __syncthreads();
   }
   if (tid == 0) {
     S.stats[0] = st_s1_ret; S.stats[1] = st_s1_it; S.stats[2] = st_s1_ev; S.stats[3] = st_s2_ret;
