@@ -19,6 +19,7 @@ class MomaTrajOptHip {
     topay_params_t p;
     topay_default_params(&p);        // == optimizer.yaml + MomaParam defaults; override fields from opt_param when they differ
     if (topay_create(&p, device, &ctx_) != TOPAY_OK) throw std::runtime_error(topay_last_error());
+    topay_set_latency_mode(ctx_, 1);   // a planning call is a handful of candidates: helper waves in every evaluation (same bits)
     setMap(map);
   }
   ~MomaTrajOptHip() { topay_destroy(ctx_); }

@@ -18,10 +18,14 @@ from topay_amd import api
 from harness import workload as wl
 
 
+LATENCY_MODE = 0   # (set by the helper-wave variant of the CPU test)
+
+
 def _run(lib, world, lens, paths, params, groups=None, budget=0):
     opt = api.MomaTrajOptBatch(params=params, device=0, lib_path=lib)
     set_map(opt, world)
     opt.set_init_traj(lens, paths)
+    opt.set_latency_mode(LATENCY_MODE)
     if groups is not None:
         opt.set_groups(groups, budget)
     ok = opt.optimize()
@@ -66,6 +70,13 @@ def test_cancellation_rule_on_cpu(cuboids_small):
     p.alm_tolerance = 10.0            # every capped solve "succeeds": the rule needs accepted candidates
     groups = np.array([0, 0, 0, 1, 1, -1], dtype=np.int32)
     _check_rule(EMU_LIB, cs["world"], cs["lens"], cs["paths"], p, groups)
+
+
+def test_cancellation_rule_with_helper_waves_on_cpu(cuboids_small, monkeypatch):
+    """The same through the helper-wave kernels (topay_set_latency_mode 2): wave 0 takes the interruption and releases the others."""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "LATENCY_MODE", 2)
+    test_cancellation_rule_on_cpu(cuboids_small)
 
 
 def test_cancellation_rule_with_a_two_wave_candidate_on_cpu(cuboids_small):

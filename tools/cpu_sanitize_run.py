@@ -61,5 +61,12 @@ o5 = api.MomaTrajOptBatch(params=p2, lib_path=LIB)
 o5.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, 0)
 o5.optimizeTraj(np.array([len(q) for q in lp], dtype=np.int32), np.concatenate(lp))
 print("multi-wave", o5.n_pieces().tolist(), o5.stats()[:, :3].tolist())
+lq = [serpentine_path(9.0), serpentine_path(19.5), serpentine_path(27.0)]
+o6 = api.MomaTrajOptBatch(params=p2, lib_path=LIB)
+o6.set_map(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d, 0)
+o6.set_init_traj(np.array([len(q) for q in lq], dtype=np.int32), np.concatenate(lq))
+o6.set_latency_mode(2)
+o6.optimize()
+print("helper waves", o6.n_pieces().tolist(), o6.last_helper_launches(), o6.stats()[:, :3].tolist())
 print("yaml", api.params_from_yaml_c("second_stage:\n  time_weight: 51.0\n  lbfgs: {past: 4}\n", lib=api.load(LIB))[0].s2_time_weight)
 print("jps", [len(q) for q in o3.plan2d_jps(tb.paths[offs[:-1]][:3, :2], tb.paths[offs[1:] - 1][:3, :2], 0.5, map_ids=mid[:3])[0]])
