@@ -290,3 +290,33 @@ def test_rare_rows_of_a_piece_that_straddles_two_passes_keep_the_one_wave_order(
     o.set_alm(fx["lam"], fx["rho"])
     f, g = o.eval(int(fx["stage"]), fx["x"])
     assert abs(f - r[1][0]) <= 1e-11 * abs(f) and np.abs(g - r[1][1]).max() <= 1e-10 * np.abs(g).max()
+
+
+@pytest.mark.gpu
+def test_helper_wave_kernels_on_512_benchmark_candidates():
+    """64 scenarios x 8 candidates of the headline generator (4 to ~45 pieces, one map per scenario), solved to convergence by the
+    default kernels and by the helper-wave kernels (mode 2: the batch is larger than the automatic rule allows): success, counters,
+    cost, ALM state, the iterate and the feasibility gate's flags of every candidate are equal."""
+    from harness import workload as wl
+    tb = wl.TablesBatch(64, 8, base_seed=42, nthreads=8)
+    worlds = [tb.world(s_) for s_ in tb.scenarios]
+    slot = {s_: k for k, s_ in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s_] for s_ in tb.scen], dtype=np.int32)
+    res = []
+    for mode in (0, 2):
+        gpu = api.MomaTrajOptBatch(device=0)
+        w0 = worlds[0]
+        gpu.build_esdf_batch(w0.origin, w0.res, w0.dims, w0.min_b, w0.max_b, np.stack([w.occ2d for w in worlds]), np.stack([w.occ3d for w in worlds]))
+        gpu.set_init_traj(tb.lens, tb.paths, map_ids=map_ids)
+        gpu.set_latency_mode(mode)
+        ok = gpu.optimize()
+        assert (gpu.last_helper_launches() > 0) == (mode == 2)
+        res.append((ok, gpu.stats(), np.nan_to_num(gpu.traj_cost), gpu.alm_state(), gpu.check_feasible(),
+                    [gpu.get_x(b) for b in range(len(tb.lens))], gpu.n_pieces()))
+        gpu.close()
+    a, h = res
+    assert a[6].max() > 32 and (a[6] <= 10).sum() > 100 and ((a[6] > 21) & (a[6] <= 32)).sum() > 3, np.bincount(a[6])
+    for k in range(5):
+        assert (a[k] == h[k]).all(), k
+    for xa, xh in zip(a[5], h[5]):
+        assert (xa == xh).all()
