@@ -373,7 +373,7 @@ def main():
         ok1 = o1.optimize()
         ms1, _ = o1.last_kernel_ms()
         cost1, stats1 = np.nan_to_num(o1.traj_cost.copy()), o1.stats().copy()
-        # the same call on the helper-wave kernels (topay_set_latency_mode 1: a batch of at most one candidate per compute unit
+        # the same call on the helper-wave kernels (topay_set_latency_mode 1: a batch of at most one candidate per SIMD
         # runs on four-wave workgroups whose extra waves join the evaluations only): same bits, shorter solves
         o1.set_latency_mode(1)
         o1.reset()

@@ -453,8 +453,9 @@ topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */)
 topay_status topay_optimize_within(topay_ctx* ctx, double budget_ms, int* timed_out);
 
 /* A planning call on an otherwise idle device (BASELINE configs[1]: 64 candidates of one scenario; planner.cpp:930-958 runs its
- * handful of candidates one after the other).  mode 1: a batch with at most one candidate per compute unit runs its candidates of
- * up to 32 pieces on workgroups of four waves -- the one-wave solver on the first, all four in every cost / gradient evaluation
+ * handful of candidates one after the other).  mode 1: a batch with at most one candidate per SIMD of the device (1024 on an MI355X: up
+ * to there the longest candidate decides the time of the batch, measured) runs its candidates of up to 32 pieces on workgroups of
+ * four waves -- the one-wave solver on the first, all four in every cost / gradient evaluation
  * (the sample passes of the two sweeps side by side).  Results are those of the default kernels bit for bit (the evaluation is
  * order-identical for any number of waves, the solver is the one-wave solver); what changes is the time of a solve.  mode 2: for
  * every batch (tests); mode 0 (the default): never.  Takes effect at the next topay_optimize / topay_optimize_async. */

@@ -705,7 +705,7 @@ class MomaTrajOptBatch:
         _chk(self.L, self.L.topay_set_groups(self.h, _ip(g), int(cancel_budget) if g is not None else 0))
 
     def set_latency_mode(self, mode):
-        """0: never (default); 1: batches with at most one candidate per compute unit run on four-wave workgroups whose extra
+        """0: never (default); 1: batches with at most one candidate per SIMD (1024 on an MI355X) run on four-wave workgroups whose extra
         waves join the evaluations only (same bits, shorter solves); 2: every batch."""
         _chk(self.L, self.L.topay_set_latency_mode(self.h, int(mode)))
 

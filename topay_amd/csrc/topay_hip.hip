@@ -215,7 +215,7 @@ struct topay_ctx {
   int n_gate = 0;            // ... of which the dispatch gate waits for (the classes of up to 32 pieces)
   bool gate = true;
   bool gate_in_solve = true;   // feasibility gate by the solving wave (TOPAY_GATE_IN_SOLVE=0: the separate kernel only)
-  int latency_mode = 0;        // topay_set_latency_mode: 0 never, 1 batches of at most one candidate per compute unit, 2 always
+  int latency_mode = 0;        // topay_set_latency_mode: 0 never, 1 batches of at most one candidate per SIMD, 2 always
   bool gate_done = false;      // the resident flags / report are those of the last solve
   // cancellation: planning call of every candidate, the window after a call's first feasible success (piece-evaluations)
   std::vector<int> h_group;
@@ -1236,11 +1236,11 @@ static topay_status launch_classes(topay_ctx* c, bool persistent, Args... args) 
     off += nk;
     // helper-wave kernels (topay_set_latency_mode): a one-wave class of a small batch runs on four-wave workgroups whose
     // extra waves only join the evaluations -- same bits, shorter sample sweeps
-    const bool lat = !EVAL && ct[k].lat && (c->latency_mode == 2 || (c->latency_mode == 1 && c->B <= c->simd_slots / 4));
+    const bool lat = !EVAL && ct[k].lat && (c->latency_mode == 2 || (c->latency_mode == 1 && c->B <= c->simd_slots));
     size_t lds = class_lds_bytes(ct[k], nm);
     if (lat) {
       lds = (size_t)(lds_doubles_mw(nm, kLatWaves) + 8 + 40 + TOPAY_CMD_DOUBLES) * sizeof(double);
-      grid = nk;   // a workgroup per candidate of the class (at most one per compute unit in mode 1)
+      grid = nk;   // a workgroup per candidate of the class
     }
     if (k == topay_ctx::NBUCKET - 2 && !c->cls[topay_ctx::NBUCKET - 1].empty() && c->bstream[k] == c->stream)
       HIPCHK(hipStreamCreateWithFlags(&c->bstream[k], hipStreamNonBlocking));   // both long classes in one batch: they must not serialise
