@@ -2,7 +2,9 @@
 // with two resident waves: streams of INDEPENDENT v_fma_f64 / v_mul_f64 / v_add_f64 (and v_fma_f32 / v_mov_b32 for scale),
 // timed with the shader clock inside the kernel and with events around it.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_f64_rate tools/valu_f64_rate.hip && /tmp/valu_f64_rate
-// Output: cycles per wave instruction seen by one wave, and per SIMD (= that / resident waves), for each kind.
+// Output: cycles per wave instruction seen by one wave, and per SIMD (= that / resident waves), for each kind; one kind per
+// process with an argument (`valu_f64_rate 12`), 100 = the code-size sweep.  (An EXEC-mask kind -- s_and_saveexec_b64 with an
+// undefined VCC inside the loop -- hung the process on the GPU and was removed.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,7 +45,6 @@ __global__ void __launch_bounds__(64, 2) k_rate(int trips, double seed, double* 
         else if (KIND == 15) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(a[i]) : "v"(c));
         else if (KIND == 16) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(f[i]));
         else if (KIND == 17) asm volatile("v_cvt_i32_f64 %0, %1" : "+v"(f[i]) : "v"(a[i]));
-        else if (KIND == 18) asm volatile("s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]" : : : "s20", "s21");
         else if (KIND == 19) asm volatile("v_readlane_b32 s20, %0, 63" : : "v"(f[i]) : "s20");
         else if (KIND == 21) asm volatile("s_load_dwordx2 s[20:21], %3, 0x0\n s_waitcnt lgkmcnt(0)\n v_fma_f64 %0, %0, s[20:21], %2" : "+v"(a[i]) : "v"(m), "v"(c), "s"(out) : "s20", "s21");
         else if (KIND == 22) asm volatile("s_load_dwordx2 s[20:21], %3, 0x0\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n s_waitcnt lgkmcnt(0)\n v_fma_f64 %0, %0, s[20:21], %2" : "+v"(a[i]) : "v"(m), "v"(c), "s"(out) : "s20", "s21");
@@ -163,7 +164,6 @@ int main(int argc, char** argv) {
     if (only < 0 || only == 5) run<5>("cndmask vcc", w, out, cyc);
     if (only < 0 || only == 7) run<7>("cndmask sgpr", w, out, cyc);
     if (only < 0 || only == 9) run<9>("cmp+cndmask", w, out, cyc);
-    if (only < 0 || only == 18) run<18>("saveexec+or", w, out, cyc);
     if (only < 0 || only == 19) run<19>("v_readlane", w, out, cyc);
     if (only < 0 || only == 20) run<20>("fma64+s_mov", w, out, cyc);
     if (only < 0 || only == 21) run<21>("s_load,wait,fma", w, out, cyc);
