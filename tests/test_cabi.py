@@ -277,3 +277,33 @@ def test_shared_map_slots_are_invalidated_when_the_owner_refills_or_goes_away(cu
     with pytest.raises(api.TopayError):
         a.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
     a.close()
+
+
+def test_a_slot_shared_from_a_sharer_follows_the_context_that_holds_the_fields(cuboids_small):
+    """A owns the fields, B shares A's slot, C shares the slot from B: C's descriptor points at A's buffers, so it is A's
+    refill or destruction that must take the slot away from C -- B going away must not."""
+    from conftest import EMU_LIB, set_map
+    cs = cuboids_small
+    a = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    set_map(a, cs["world"])
+    b = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    b.share_maps(a, 0, 1)
+    c = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    c.share_maps(b, 0, 1)
+    c.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    x = c.get_x(0)
+    f0 = c.eval(1, 0, x)[0]
+    b.close()                                        # the middle context goes away: the fields are A's and stay
+    assert c.eval(1, 0, x)[0] == f0
+    set_map(a, cs["world"])                          # the holder refills the slot: C loses it
+    with pytest.raises(api.TopayError):
+        c.eval(1, 0, x)
+    with pytest.raises(api.TopayError):
+        c.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    c.share_maps(a, 0, 1)
+    c.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    assert c.eval(1, 0, x)[0] == f0
+    a.close()
+    with pytest.raises(api.TopayError):
+        c.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
+    c.close()

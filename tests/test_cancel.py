@@ -208,3 +208,42 @@ def test_wall_clock_budget_interrupts_what_has_not_finished():
     st = gpu.stats()
     assert (st[intr, 3] == -2000).all()
     tb.close()
+
+
+@pytest.mark.gpu
+def test_wall_clock_budget_does_not_start_what_is_still_queued():
+    """A batch several times larger than the resident grid: when the deadline of topay_optimize_within passes, the candidates
+    still in the queues must not be begun at all (they used to be dequeued and run through the whole of stage 1
+    one after the other, so the overshoot grew with the queue).  They come back interrupted with no evaluation counted, and
+    the call returns within a small multiple of the budget."""
+    import time
+
+    tb = wl.TablesBatch(768, 8, base_seed=7, nthreads=8)
+    gpu = api.MomaTrajOptBatch(device=0)
+    worlds = [tb.world(s_) for s_ in tb.scenarios]
+    w0 = worlds[0]
+    gpu.build_esdf_batch(w0.origin, w0.res, w0.dims, w0.min_b, w0.max_b, np.stack([w.occ2d for w in worlds]), np.stack([w.occ3d for w in worlds]))
+    slot = {s_: k for k, s_ in enumerate(tb.scenarios)}
+    map_ids = np.array([slot[s_] for s_ in tb.scen], dtype=np.int32)
+    ok_full = gpu.optimizeTraj(tb.lens, tb.paths, map_ids=map_ids)
+    ms_full = gpu.last_kernel_ms()[0]
+    assert len(ok_full) >= 3 * 1024                 # (more candidates than SIMD slots: most of them wait in the queues at first)
+    gpu.reset()
+    budget = max(2.0, 0.05 * ms_full)
+    t0 = time.perf_counter()
+    ok_short, timed_out = gpu.optimize_within(budget)
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    intr = gpu.interrupted().astype(bool)
+    st = gpu.stats()
+    never = intr & (st[:, 2] == 0) & (st[:, 5] == 0)
+    print(f"full solve {ms_full:.0f} ms; budget {budget:.0f} ms -> returned after {wall_ms:.0f} ms; {int(intr.sum())} of {len(intr)} interrupted, "
+          f"{int(never.sum())} of them never begun")
+    assert timed_out and never.sum() > 0.3 * len(intr)
+    assert (st[intr, 3] == -2000).all() and not ok_short[intr].any()
+    assert np.isnan(gpu.traj_cost[never]).all()
+    # what was resident at the deadline finishes its stage 1 (no interruption point there) and one stage-2 iteration
+    assert wall_ms < budget + 0.35 * ms_full, (wall_ms, budget, ms_full)
+    gpu.reset()
+    ok2 = gpu.optimize()
+    assert (ok2 == ok_full).all() and not gpu.interrupted().any()
+    tb.close()

@@ -48,6 +48,15 @@ static void set_err(const std::string& s) { g_err = s; }
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
 static const char* exp_env(const char*) { return nullptr; }
+// A tuning switch in the environment of the product library would be silently ignored (an A/B script then measures the
+// same build twice): say so, once per process, when the library is loaded.
+__attribute__((constructor)) static void topay_warn_ignored_switches() {
+  static const char* names[] = {"TOPAY_DISPATCH_GATE", "TOPAY_EDT_ENVELOPE", "TOPAY_FORCE_CLASS", "TOPAY_GATE_IN_SOLVE", "TOPAY_LDS_PAD",
+                                "TOPAY_OCC2_GAIN", "TOPAY_OVERSUBSCRIBE", "TOPAY_POISON", "TOPAY_RESERVE_SLOTS", "TOPAY_SHARE_BIAS0",
+                                "TOPAY_MW_C4", "TOPAY_MW_C5"};
+  for (const char* n : names)
+    if (getenv(n)) fprintf(stderr, "libtopay_hip: %s is set but ignored -- tuning switches exist only in -DTOPAY_EXPERIMENTS builds (tools/ab_lib.sh)\n", n);
+}
 #endif
 
 struct DevBuf {
@@ -556,7 +565,7 @@ void topay_destroy(topay_ctx* c) {
   DevBuf* bufs[] = {&c->dmaps, &c->paths, &c->path_off, &c->path_len, &c->bvel, &c->bacc, &c->scratch, &c->N, &c->s1_past,
                     &c->map_id, &c->head, &c->tail, &c->start_xy, &c->goal_xy, &c->init_xy, &c->x0, &c->x, &c->work,
                     &c->hist_s, &c->hist_y, &c->hist_ys, &c->hist_alpha, &c->lu, &c->poff, &c->noff, &c->group_id, &c->group_tau, &c->interrupted, &c->success, &c->cost, &c->stats,
-                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
+                    &c->xyerr, &c->coef, &c->T, &c->knots, &c->alm, &c->fout, &c->order, &c->trace, &c->elapsed, &c->startus, &c->hwid, &c->sbuf, &c->mstash, &c->feas_cseq, &c->feas_tk, &c->feas_report, &c->feas_flags, &c->edt_occ, &c->edt_tmp1,
                     &c->edt_tmp2, &c->edt_v, &c->edt_z, &c->edt_out2, &c->edt_out3, &c->pb_io, &c->qnext, &c->mc_i, &c->mc_d, &c->mc_k, &c->mc_rs, &c->mc_in};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < TOPAY_MAX_MAPS; i++) { c->map2d[i].release(); c->map3d[i].release(); c->map2d_inf[i].release(); c->map2d_crit[i].release(); }
@@ -627,11 +636,12 @@ extern "C" topay_status topay_share_maps(topay_ctx* c, topay_ctx* owner, int fir
     c->map2d[m].release(); c->map3d[m].release(); c->map2d_inf[m].release(); c->map2d_crit[m].release();   // own copies of these slots, if any
     c->hmaps[m] = owner->hmaps[m];
     c->have_map[m] = 1;
-    c->map_owner[m] = owner;
-  }
-  {
+    // A slot that `owner` itself only shares is registered with the context that holds the fields (the root): it is the
+    // root's refill / destroy that frees them, and its list of sharers is the one invalidate_sharers walks.
+    topay_ctx* root = owner->map_owner[m] ? owner->map_owner[m] : owner;
+    c->map_owner[m] = root;
     std::lock_guard<std::mutex> lk(g_registry_mutex);
-    if (std::find(owner->map_sharers.begin(), owner->map_sharers.end(), c) == owner->map_sharers.end()) owner->map_sharers.push_back(c);
+    if (std::find(root->map_sharers.begin(), root->map_sharers.end(), c) == root->map_sharers.end()) root->map_sharers.push_back(c);
   }
   for (size_t i = 0; i < c->map_arenas.size();) {   // arenas of own builds that only held these slots
     topay_ctx::MapArena& a = c->map_arenas[i];
@@ -1429,7 +1439,14 @@ topay_status topay_set_groups(topay_ctx* c, const int* group_id, int cancel_budg
     if (had_groups) return upload_order(c, false);   // back to longest first
     return TOPAY_OK;
   }
-  if (!c->gate_in_solve) { set_err("cancellation needs the in-solve feasibility gate (TOPAY_GATE_IN_SOLVE=0 is set)"); return TOPAY_ERR_UNSUPPORTED; }
+  if (!c->gate_in_solve) { set_err("cancellation needs the in-solve feasibility gate (switched off in this experiments build: TOPAY_GATE_IN_SOLVE=0)"); return TOPAY_ERR_UNSUPPORTED; }
+  // The in-solve gate's scratch is the candidate's dead L-BFGS history block (mem_size x n doubles twice); a candidate whose
+  // block is too short is left to the separate kernel and would never publish its call's clock: the window would silently
+  // stay shut.  64 rows hold the gate's panels and sample times of a trajectory three times as long as its initial guess.
+  if (std::max(c->hp.s1_lbfgs.mem_size, c->hp.s2_lbfgs.mem_size) < 64) {
+    set_err("cancellation window: the L-BFGS mem_size must be at least 64 (the in-solve gate works in the history block)");
+    return TOPAY_ERR_INVALID_ARG;
+  }
   // the caller's ids (any integers >= 0, e.g. global scenario numbers of a sharded sweep; -1 = no planning call) become
   // dense indices: the device holds one clock per planning call that is present, not one per possible id
   std::vector<int> dense(c->B, -1);
@@ -2161,7 +2178,12 @@ topay_status topay_eval_waves(topay_ctx* c, int stage, int i, int waves, const d
 // trajectory.  Replay and warm-start entry; the cost stored is the stage-2 cost at x.
 topay_status topay_load_solution(topay_ctx* c, int i, const double* x, const double* alm_lambda, const double* alm_rho) {
   topay_status s = eval_one(c, 2, i, x, alm_lambda, alm_rho, nullptr, nullptr, nullptr, true);
-  if (s == TOPAY_OK) { c->solved = true; c->gate_done = false; }   // (the gate of a loaded trajectory: the separate kernel)
+  if (s == TOPAY_OK) {
+    c->solved = true;
+    c->gate_done = false;   // (the gate of a loaded trajectory: the separate kernel)
+    const int zero = 0;     // the candidate has a trajectory now, whatever a solve before left in its flag
+    HIPCHK(memcpy_sync(c, c->interrupted.as<int>() + i, &zero, 4, hipMemcpyHostToDevice));
+  }
   return s;
 }
 
@@ -2234,8 +2256,16 @@ topay_status topay_feasibility_report(topay_ctx* c, int* feasible, int* strict, 
                      c->feas_tk.as<double>(), cap_panels, cap_samples, c->feas_report.as<double>(), c->feas_flags.as<int>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  std::vector<int> fl((size_t)B * 2);
+  std::vector<int> fl((size_t)B * 2), intr(B);
   HIPCHK(memcpy_sync(c, fl.data(), c->feas_flags.p, fl.size() * 4, hipMemcpyDeviceToHost));
+  // an interrupted candidate has no trajectory (its result block holds the spline of the evaluation it was stopped in):
+  // its verdicts stay 0 / 0, as the in-solve path and the cancellation post-pass of topay_synchronize write them
+  HIPCHK(memcpy_sync(c, intr.data(), c->interrupted.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+  bool changed = false;
+  for (int b = 0; b < B; b++)
+    if (intr[b] && (fl[2 * b] || fl[2 * b + 1])) { fl[2 * b] = 0; fl[2 * b + 1] = 0; changed = true; }
+  if (changed) HIPCHK(memcpy_sync(c, c->feas_flags.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice));
+  c->gate_done = true;   // resident until the next solve, load or re-initialisation (each resets it)
   for (int b = 0; b < B; b++) {
     if (feasible) feasible[b] = fl[2 * b];
     if (strict) strict[b] = fl[2 * b + 1];

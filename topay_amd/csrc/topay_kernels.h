@@ -269,20 +269,42 @@ __device__ __forceinline__ void drain_queues(const DevBatch& B, const DevMap* ma
   for (int cls = my_class; cls >= lowest; cls--) {
     const int count = queued ? B.queue_count[cls] : 1, off = queued ? B.queue_off[cls] : (int)blockIdx.x;
     for (int once = 0;; once++) {
+      // thread 0 takes the next position and looks at topay_cancel's flag (threads.interrupt_all(): a candidate that has not
+      // begun when the flag is up is not begun -- a batch larger than the resident grid would otherwise run the whole of
+      // stage 1 of every queued candidate after the deadline of topay_optimize_within); bit 30 carries the verdict
       int pos = 0;
-      if (queued) {
-        if (threadIdx.x == 0) pos = atomicAdd(B.queue_next + cls, 1);
-        if (NWE == 1) {
-          pos = __shfl(pos, 0);
-        } else {   // the position travels to the other waves through the first LDS word (nothing of a solve is live here)
-          TOPAY_LDS int* w0 = (TOPAY_LDS int*)TOPAY_LDS_PTR;
-          if (threadIdx.x == 0) w0[0] = pos;
-          __syncthreads();
-          pos = w0[0];
-          __syncthreads();
+      if (threadIdx.x == 0) {
+        pos = queued ? atomicAdd(B.queue_next + cls, 1) : once;
+        int stop = 0;
+#ifndef TOPAY_CPU_EMU
+        if (B.cancel_flag) stop = __hip_atomic_load(B.cancel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+#else
+        if (B.cancel_flag) stop = *B.cancel_flag != 0;
+#endif
+        pos = (pos < 0x40000000 ? pos : 0x3fffffff) | (stop << 30);
+      }
+      if (NWE == 1) {
+        pos = __shfl(pos, 0);
+      } else {   // the position travels to the other waves through the first LDS word (nothing of a solve is live here)
+        TOPAY_LDS int* w0 = (TOPAY_LDS int*)TOPAY_LDS_PTR;
+        if (threadIdx.x == 0) w0[0] = pos;
+        __syncthreads();
+        pos = w0[0];
+        __syncthreads();
+      }
+      const bool cancelled = (pos & 0x40000000) != 0;
+      pos &= 0x3fffffff;
+      if (cancelled && pos < count) {   // interrupted before its first evaluation: no trajectory, success 0, verdicts 0 / 0
+        if (threadIdx.x == 0) {
+          const int b = B.order[off + pos];
+          int* st = B.stats + (size_t)b * 8;
+          for (int q = 0; q < 8; q++) st[q] = 0;
+          st[3] = TOPAY_INTERRUPTED;
+          if (B.interrupted) B.interrupted[b] = 1;
+          B.success[b] = 0;
+          if (B.gate_in_solve) { B.feas_flags[2 * b] = 0; B.feas_flags[2 * b + 1] = 0; }
         }
-      } else {
-        pos = once;
+        continue;
       }
       if (pos >= count) break;
       solve_one<RMAX, NW, OCC, NWE, RMAX_E>(B, maps, Nmax_lds, B.order[off + pos]);
