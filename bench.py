@@ -478,7 +478,7 @@ def main():
             "winners_per_step": int(winners.get("n", 0)),
             "d2h_winner_bytes_per_step": int(sum(v.nbytes for v in winners["last"].values())) if "last" in winners else 0,
             "record_gather": (dict(gather_stats, collective=("RCCL" if backend == "nccl" else backend) + " all-gather of 6 x f64 per scenario",
-                                   rows_expected=int(S * world), scenario_ids_distinct=int(gather_stats.get("distinct_ids", 0)))
+                                   rows_expected=int(S * world), world=int(world), scenario_ids_distinct=int(gather_stats.get("distinct_ids", 0)))
                               if distributed else None),
             "ranks": rank_report,
             "setup_seconds_untimed": setup_s,

@@ -4,9 +4,17 @@
 // scenario's record and its all-gather over RCCL (the multi-GPU exchange, world size 1), then the front-end chain
 // start / goal -> 2-D path -> dense path -> joint-space search -> trajectory around a wall.
 //   g++ -std=c++17 -Iinclude examples/cabi_demo.cpp -o /tmp/cabi_demo topay_amd/lib/libtopay_hip.so -Wl,-rpath,$PWD/topay_amd/lib
+// `cabi_demo --exchange <rank> <world> <id file>`: only the record exchange, one process per GPU of a node (rank r on device
+// r): rank 0 creates the communicator id and leaves it in the file, the others wait for it -- the out-of-band step a planner
+// does over whatever it has (a file, a pipe, a ROS parameter).  Ranks contribute different numbers of records.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "topay.h"
@@ -20,7 +28,64 @@
     }                                                                      \
   } while (0)
 
-int main() {
+static int run_exchange(int rank, int world, const char* id_file) {
+  topay_params_t p;
+  CHECK(topay_default_params(&p));
+  topay_ctx* ctx = nullptr;
+  CHECK(topay_create(&p, rank, &ctx));
+  topay_comm_id_t id;
+  if (rank == 0) {
+    CHECK(topay_comm_unique_id(&id));
+    const std::string tmp = std::string(id_file) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+    std::fclose(f);
+    if (std::rename(tmp.c_str(), id_file) != 0) { std::fprintf(stderr, "cannot publish %s\n", id_file); return 1; }
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 600 && !got; tries++) {   // up to a minute
+      if (FILE* f = std::fopen(id_file, "rb")) {
+        got = std::fread(&id, sizeof(id), 1, f) == 1;
+        std::fclose(f);
+      }
+      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    if (!got) { std::fprintf(stderr, "rank %d: no communicator id in %s\n", rank, id_file); return 1; }
+  }
+  CHECK(topay_comm_init(ctx, &id, world, rank));
+  // rank r holds 2 + r records with ids 100 r + i; blocks of per_rank = 2 + world entries
+  const int n_mine = 2 + rank, per_rank = 2 + world;
+  std::vector<topay_record_t> mine(n_mine), all((size_t)world * per_rank);
+  for (int i = 0; i < n_mine; i++) {
+    mine[i].scenario_id = 100 * rank + i;
+    mine[i].best_candidate = i % 3 - 1;
+    mine[i].status = mine[i].best_candidate >= 0;
+    mine[i].n_pieces = 4 + i;
+    mine[i].cost = 10.0 * rank + i;
+    mine[i].duration = 5.5 + rank;
+  }
+  int n_all = 0, bad = 0, expect = 0;
+  for (int round = 0; round < 3; round++) {   // the exchange is per step: the communicator is reused
+    CHECK(topay_gather_records(ctx, mine.data(), n_mine, per_rank, all.data(), &n_all));
+    expect = 0;
+    for (int r = 0; r < world; r++)
+      for (int i = 0; i < 2 + r; i++, expect++) {
+        const topay_record_t& q = all[expect];
+        if (expect >= n_all || q.scenario_id != 100 * r + i || q.best_candidate != i % 3 - 1 || q.n_pieces != 4 + i || q.cost != 10.0 * r + i ||
+            q.duration != 5.5 + r)
+          bad++;
+      }
+    if (n_all != expect) bad++;
+  }
+  std::printf("rank %d of %d on device %d: record gather over RCCL, %d records from %d ranks: %s\n", rank, world, rank, n_all, world,
+              bad ? "MISMATCH" : "ok");
+  CHECK(topay_comm_destroy(ctx));
+  topay_destroy(ctx);
+  return bad ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 5 && std::strcmp(argv[1], "--exchange") == 0) return run_exchange(std::atoi(argv[2]), std::atoi(argv[3]), argv[4]);
   topay_params_t p;
   CHECK(topay_default_params(&p));
   topay_ctx* ctx = nullptr;

@@ -105,6 +105,9 @@ def test_cpp_caller_runs_on_the_device(tmp_path):
     # the front-end chain through the C-ABI: 2-D path around the wall, dense path, joint-space search, trajectory
     fe = [ln for ln in r.stdout.splitlines() if ln.startswith("front-end:")]
     assert len(fe) == 2 and "joint search status 1" in fe[0] and "trajectory success 1" in fe[1], r.stdout
+    # the several-processes mode of the exchange (tests/test_sharding.py runs it with two ranks where there are two GPUs) as one rank
+    r = subprocess.run([exe, "--exchange", "0", "1", str(tmp_path / "comm.id")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rank 0 of 1 on device 0: record gather over RCCL, 2 records from 1 ranks: ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_header_is_plain_c99():

@@ -153,3 +153,56 @@ def test_bench_with_two_ranks_on_the_one_gpu():
     assert (ranks[1]["scenario_id_min"], ranks[1]["scenario_id_max"]) == (64, 127)
     assert ranks[0]["input_sha"] != ranks[1]["input_sha"]          # different seeds per rank
     assert ranks[0]["solved"] == ranks[1]["solved"] == 512
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()     # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_over_rccl():
+    """The same two-rank bench over the **nccl** backend: a real RCCL communicator between two GPUs (ncclAllGather of the
+    records over xGMI).  Skips on a one-GPU box -- the pool's boxes have one; the test is here for the day the suite runs on a
+    node with several (no 1 -> 8 curve has been measured by this project)."""
+    import json
+
+    if _gpus() < 2:
+        pytest.skip("needs two GPUs: an RCCL communicator cannot have two ranks on one device")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TOPAY_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29521", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scenarios", "64",
+           "--no-cpu-baseline", "--no-config1", "--no-serial", "--no-planner"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    g = out["config"]["record_gather"]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["n_not_launched"] == 0
+    assert g["world"] == 2 and g["collective"].startswith("RCCL")
+    assert g["own_rows_match"] is True and g["rows"] == 128 == g["rows_expected"] and g["scenario_ids_distinct"] == 128
+    ranks = sorted(out["config"]["ranks"], key=lambda q: q["rank"])
+    assert [q["device"] for q in ranks] == [0, 1]
+    assert (ranks[0]["scenario_id_min"], ranks[0]["scenario_id_max"]) == (0, 63)
+    assert (ranks[1]["scenario_id_min"], ranks[1]["scenario_id_max"]) == (64, 127)
+    assert ranks[0]["input_sha"] != ranks[1]["input_sha"]
+
+
+@pytest.mark.gpu
+def test_cpp_callers_exchange_records_between_two_gpus(tmp_path):
+    """examples/cabi_demo.cpp --exchange: two C++ processes, one per GPU, through topay_comm_unique_id (rank 0; the id travels in
+    a file) / topay_comm_init / topay_gather_records -- the library's own ncclAllGather with unequal record counts, three
+    times on one communicator.  Skips on a one-GPU box."""
+    if _gpus() < 2:
+        pytest.skip("needs two GPUs: an RCCL communicator cannot have two ranks on one device")
+    from test_cabi import _build_demo
+    exe = str(tmp_path / "cabi_demo")
+    _build_demo(exe)
+    idf = str(tmp_path / "comm.id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, "--exchange", str(r), "2", idf], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} of 2 on device {r}: record gather over RCCL, 5 records from 2 ranks: ok" in o, o
