@@ -493,9 +493,11 @@ topay_status topay_gather_records(topay_ctx* ctx, const topay_record_t* mine, in
 topay_status topay_pack_records(const topay_record_t* mine, int n_mine, int per_rank, topay_record_t* block);
 topay_status topay_unpack_records(const topay_record_t* gathered, int world, int per_rank, topay_record_t* all, int* n_valid);
 
-/* Launch class of a candidate with n_pieces pieces: waves per trajectory (1, 2 or 4) and decision-vector elements per
- * thread of the kernel that solves and (topay_eval) evaluates it.  For parity tooling: the rounding of the solver's dot
- * products depends on how the vectors are divided over the threads.  Any output pointer may be NULL. */
+/* Launch class of a candidate with n_pieces pieces: the waves its SOLVER's vectors are divided over and the decision-vector
+ * elements per thread of that solver.  For parity tooling: the rounding of the solver's dot products depends on how the
+ * vectors are divided over the threads (an evaluation does not: it is order-identical for any number of waves).  Since
+ * round 5 every class solves on one wave -- the long classes (more than 32 pieces) run their evaluations on four waves and
+ * the solver on the first of them -- so *waves is 1 for every n_pieces.  Any output pointer may be NULL. */
 topay_status topay_class_of(int n_pieces, int* waves, int* elements_per_thread, int* class_index);
 
 /* Device memory (bytes) of the batch resident in the context: every block topay_set_init_traj sized.  The variable-length

@@ -125,7 +125,7 @@ def test_cancellation_rule_on_gpu_matches_oracle():
     for b in range(len(lens)):
         o = orc.Oracle(m)
         o.set_init_traj(paths[offs[b]:offs[b + 1]])
-        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=ev.class_of(o.N)[0])
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), epl=ev.class_of(o.N)[1], nw=ev.class_of(o.N)[0])
         so = o.stats()
         oclock.append((so["stage1_evals"] + so["stage2_evals"]) * o.N)
         # (in device-order mode the oracle's spline is not the one of its final iterate -- the evaluations came from the

@@ -366,7 +366,7 @@ def test_converged_solves_equal_oracle_solver_in_device_order():
     for b in range(len(lens)):
         o = orc.Oracle(m)
         o.set_init_traj(paths[offs[b]:offs[b + 1]])
-        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(o.N)[0])
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), epl=opt.class_of(o.N)[1], nw=opt.class_of(o.N)[0])
         so = o.stats()
         assert okh == bool(ok[b]), b
         assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
@@ -403,7 +403,7 @@ def test_converged_solves_of_a_benchmark_slice_equal_oracle_solver_in_device_ord
             views[sc] = orc.MapView(w.origin, w.res, w.dims, w.min_b, w.max_b, w.esdf2d, w.esdf3d)
         o = orc.Oracle(views[sc])
         o.set_init_traj(tb.paths[offs[b]:offs[b + 1]])
-        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(o.N)[0])
+        okh = o.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), epl=opt.class_of(o.N)[1], nw=opt.class_of(o.N)[0])
         so = o.stats()
         assert okh == bool(ok[b]), b
         assert [so["stage1_ret"], so["stage1_iters"], so["stage1_evals"], so["stage2_last_ret"], so["stage2_iters"], so["stage2_evals"],
@@ -489,7 +489,7 @@ def test_config5_high_resolution_esdf():
     for b in range(0, len(lens), 4):
         oh = orc.Oracle(m)
         oh.set_init_traj(paths[offs[b]:offs[b + 1]])
-        okh = oh.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), nw=opt.class_of(oh.N)[0])
+        okh = oh.optimize_device_order(lambda stage, xx, lam, rho: ev.eval(stage, b, xx, lam, rho), epl=opt.class_of(oh.N)[1], nw=opt.class_of(oh.N)[0])
         so = oh.stats()
         assert okh == bool(ok[b]) and (oh.get_x() == xs[b]).all() and (oh.alm_state() == alm[b]).all(), b
         assert [so["stage1_iters"], so["stage1_evals"], so["stage2_iters"], so["stage2_evals"], so["alm_outer"]] == \

@@ -156,8 +156,10 @@ def test_bench_with_two_ranks_on_the_one_gpu():
 
 
 def _gpus():
-    import torch
-    return torch.cuda.device_count()     # (counting devices does not initialise the GPU in this process)
+    # in a child process: torch brings its own HIP runtime and RCCL, and importing it into the test process beside the
+    # library's (the system's) ends the process with a double free at exit
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
 
 
 @pytest.mark.gpu

@@ -49,6 +49,18 @@ __constant__ DevParams g_P;
 #define TOPAY_OPAQUE_I(x) do { } while (0)
 #endif
 
+// On the functions that call the non-inlined device functions.  Those callees use the whole register file, and the
+// compiler lets such a function skip the saving of callee-saved registers (the caller then saves exactly what it keeps across
+// the call) only if no call of it carries LLVM's `tail` marker -- which the optimiser adds to every call that is handed no
+// pointer into the caller's stack frame.  Round 5 took the stack out of the manipulator block's interface, the marker
+// appeared, and the block began to save and restore all 112 callee-saved VGPRs on every call (388 scratch instructions).
+// With this attribute the marker is not added.
+#ifndef TOPAY_CPU_EMU
+#define TOPAY_CALLS_BIG_FUNCTIONS __attribute__((disable_tail_calls))
+#else
+#define TOPAY_CALLS_BIG_FUNCTIONS
+#endif
+
 // A wave-uniform `true` the compiler cannot see through (one s_cmp + s_cbranch): starts a new basic block on purpose.
 __device__ __forceinline__ bool topay_opaque_true() {
 #ifndef TOPAY_CPU_EMU
@@ -142,6 +154,18 @@ __device__ __forceinline__ void wave_global_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #else
   __builtin_amdgcn_wave_barrier();
+#endif
+}
+// The lane's number formed anew (two instructions, no operand): used after a call of the manipulator block, so that the
+// number -- and everything derived from it -- need not be carried across the call in a register the callee clobbers.
+__device__ __forceinline__ int fresh_lane_id(int known) {
+#ifndef TOPAY_CPU_EMU
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  (void)known;
+  return l;
+#else
+  return known;
 #endif
 }
 // inclusive prefix sum over lanes
@@ -689,22 +713,25 @@ __device__ __forceinline__ void joint_rotate(double* R, int i, double c_, double
   }
 }
 
-// The inputs travel in registers: two aggregates of at most 16 dwords each (a larger one is passed through the stack, i.e.
-// scratch memory: nine stores and eight loads per call), the map and the sample's 36 doubles of the candidate's
-// self-collision block in HBM (only touched by a lane whose arm really collides with itself; [sample][36], so that every
-// entry is the base plus a constant offset -- a strided layout costs a 64-bit address per entry; null: a padding lane,
-// whose results are dropped and which never writes) -- 32 dwords, the argument registers there are.
-struct ManiInA {
-  double pos[8];    // x, y, theta, q1..q5
-};
-struct ManiInB {
-  double pos8, pos9;   // q6, q7
-  double omg, step, sth, cth;
-};
+// Interface (round 5).  Nothing of the block's inputs or outputs travels through the stack any more:
+//   * in: the sample (piece i, even sample index j, local half step, step) and its XY position -- the pose (theta, q1..q7)
+//     is evaluated HERE from the coefficients in LDS (round 4 passed the ten pose values by value: 16 of the 32 argument
+//     dwords went through scratch memory because the hidden return-value pointer took the 33rd register);
+//   * out: five doubles in registers (an aggregate of at most 16 dwords is returned in VGPRs): d/dx, d/dy, d/dtheta, cost and
+//     the "/K" dJ/dT part; the seven joint entries of moma_grad go to the lane's column of seven rows of the wave's LDS pass
+//     buffer (mg_lds[q * 64], q = 0..6: the buffer is idle during the sample passes), each as soon as its torque is known --
+//     what the 12-double return value in scratch memory did for the register pressure of the block's last part, without the
+//     scratch memory.
+// e = the sample's index in the candidate's self-collision block, -1 for a padding lane (results dropped, no HBM write).
 struct ManiOut {
-  double g[10];
+  double gx, gy, gth;
   double cost, gdT;
 };
+#ifdef TOPAY_ASM_MARKS   // (probe builds: comment lines in the assembly that delimit the sections of the block)
+#define MMARK(k) asm volatile("; TOPAY_MARK " #k)
+#else
+#define MMARK(k) do { } while (0)
+#endif
 #ifdef TOPAY_STAMPS
 __device__ long long g_mani_stamps[8];
 #define MSTAMP(k)                                                                                   \
@@ -725,17 +752,30 @@ __device__ long long g_mani_stamps[8];
 // same bits as the 144-register version.  LA = spheres whose ESDF gathers are issued ahead (2 with one wave per SIMD;
 // 1 with two, where the other wave covers the latency and the request registers are what is scarce).
 template <int OCC>
-__device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, const ManiInA inA, const ManiInB inB, glb_dp in_stash) {
+__device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, lds_cdp cL, int rows, int pi, int pj, double half, double step,
+                                                  double posx, double posy, int e, glb_dp mstash, lds_dp mg_lds) {
   const DevParams& P = g_P;
   const DevMap M = load_map(mp);
+  const bool in_act = e >= 0;
+  const glb_dp in_stash = mstash + 36 * (in_act ? e : 0);
+  // pose of the sample: order-0 polynomials of theta and the seven joints (the arc length is not part of the pose), in the
+  // arithmetic of poly4 / make_basis
   double pos[10];
+  pos[0] = posx; pos[1] = posy;
+  double sth, cth;
+  {
+    const double s1 = pj * half;
+    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
 #pragma unroll
-  for (int q = 0; q < 8; q++) pos[q] = inA.pos[q];
-  pos[8] = inB.pos8; pos[9] = inB.pos9;
-  const double omg = inB.omg, step = inB.step, sth = inB.sth, cth = inB.cth;
-  const bool in_act = in_stash != nullptr;
+    for (int d = 0; d < 9; d++) {
+      if (d == 1) continue;
+      lds_cdp c = cL + d * rows + 6 * pi;
+      pos[d == 0 ? 2 : d + 1] = fma(c[5], s5, fma(c[4], s4, fma(c[3], s3, fma(c[2], s2, fma(c[1], s1, c[0])))));
+    }
+    det_sincos(pos[2], &sth, &cth);
+  }
+  const double omg = (pj == 0 || pj == 2 * TOPAY_K) ? 0.5 : 1.0;
   ManiOut out;
-  double* moma_grad = out.g;
   double cost, gdTk;
   const double mu = P.relu_mu;
   const double w = omg * step;
@@ -749,6 +789,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     TOPAY_SCHED_FENCE();
   }
   MSTAMP(0);  // 7 sincos
+  MMARK(0);
   double A[9];
   {
     const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
@@ -788,6 +829,12 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     }
   }
   MSTAMP(1);  // walk 1
+  MMARK(1);
+  // The joints' cosines wait in the lane's LDS column (the seven words that take the torques at the end) while the sphere
+  // loop needs the registers: walk 2a reads them from there, walk 2b reads word i before torque i is written to it.  (They
+  // and the sines used to be spilled to scratch memory across the loop by the compiler: 14 of the block's 25 spilled values.)
+#pragma unroll
+  for (int i = 0; i < 7; i++) mg_lds[i * 64] = cq[i];
   cost = 0.0;
   gdTk = 0.0;
   const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
@@ -846,6 +893,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     }
   }
   MSTAMP(2);  // sphere pairs
+  MMARK(2);
   // chassis top (spheres with index > 2, 1525-1539) and environment collision (1477-1520)
   double bFx = 0.0, bFy = 0.0, bMz = 0.0;  // base: x, y, yaw (everything rotates about the vertical axis through (x, y))
   constexpr int LA = OCC >= 2 ? TOPAY_ESDF_LOOKAHEAD_OCC2 : TOPAY_ESDF_LOOKAHEAD;  // spheres whose gathers are issued ahead
@@ -907,9 +955,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     TOPAY_SCHED_FENCE();
   }
   MSTAMP(3);  // ESDF loop
-  moma_grad[0] = bFx;
-  moma_grad[1] = bFy;
-  moma_grad[2] = bMz;
+  MMARK(3);
   // joints: tau_i = u_i . (Mo_beyond - o_{i+1} x F_beyond) with F, Mo = sums of g' and rho x g'.
   // walk 2a accumulates the totals, walk 2b peels off the links at or below each joint.
   double Fx = 0, Fy = 0, Fz = 0, Mx = 0, My = 0, Mz = 0;
@@ -933,7 +979,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       q1 = fma(R[5], P.colli_length[i], q1);
       q2 = fma(R[8], P.colli_length[i], q2);
       if (i == 7) break;
-      joint_rotate(R, i, cq[i], sq[i]);
+      joint_rotate(R, i, mg_lds[i * 64], sq[i]);
       TOPAY_SCHED_FENCE();
     }
   }
@@ -956,19 +1002,22 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
       o0 = fma(R[2], P.colli_length[i], o0);
       o1 = fma(R[5], P.colli_length[i], o1);
       o2 = fma(R[8], P.colli_length[i], o2);
+      const double cqi_ = mg_lds[i * 64];   // (read before the torque takes the word)
       // joint i turns frame i about its local z (even i) or y (odd i) axis through o_{i+1}
       const int ac = (i % 2 == 0) ? 2 : 1;
       const double ax = R[0 * 3 + ac], ay = R[1 * 3 + ac], az = R[2 * 3 + ac];
       const double tx = Mx - fma(o1, Fz, -(o2 * Fy));
       const double ty = My - fma(o2, Fx, -(o0 * Fz));
       const double tz = Mz - fma(o0, Fy, -(o1 * Fx));
-      moma_grad[3 + i] = fma(az, tz, fma(ay, ty, ax * tx));
-      joint_rotate(R, i, cq[i], sq[i]);
+      mg_lds[i * 64] = fma(az, tz, fma(ay, ty, ax * tx));
+      joint_rotate(R, i, cqi_, sq[i]);
       TOPAY_SCHED_FENCE();
     }
   }
   MSTAMP(4);  // walks 2a/2b
-  // joint position limits — moma_traj_opt.cpp:1616-1666 (symmetric joint_pos_limit_max, reference quirk)
+  MMARK(4);
+  // joint position limits — moma_traj_opt.cpp:1616-1666 (symmetric joint_pos_limit_max, reference quirk); the rare
+  // contribution to a joint's entry is a read-modify-write of the lane's own LDS word
   const double wJP = P.s2_mani_pos_weight;
 #pragma unroll
   for (int ji = 0; ji < 7; ji++) {
@@ -976,7 +1025,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     if (v > 0) {
       double pe, pd;
       smoothL1(v, mu, pe, pd);
-      moma_grad[ji + 3] += w * wJP * pd;
+      mg_lds[ji * 64] += w * wJP * pd;
       gdTk += omg * wJP * (pe * TOPAY_INV_K);
       cost += w * wJP * pe;
     }
@@ -984,12 +1033,16 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, co
     if (v > 0) {
       double pe, pd;
       smoothL1(v, mu, pe, pd);
-      moma_grad[ji + 3] -= w * wJP * pd;
+      mg_lds[ji * 64] -= w * wJP * pd;
       gdTk += omg * wJP * (pe * TOPAY_INV_K);
       cost += w * wJP * pe;
     }
   }
   MSTAMP(5);  // joint limits
+  MMARK(5);
+  out.gx = bFx;
+  out.gy = bFy;
+  out.gth = bMz;
   out.cost = cost;
   out.gdT = gdTk;
   return out;
@@ -1070,61 +1123,31 @@ __device__ __forceinline__ void basis_k(int k, double s, double& b0, double& b1,
 // Body of one even Simpson sample (i, j) of sweep 1: kinodynamic penalties, and in stage 2 the chassis ESDF query, the
 // manipulator block and the joint velocity / acceleration limits.  Outputs the per-sample gradient rows gB[12]
 // (theta orders 0-2, s orders 1-2, joints order 0), the sample's dJ/dT part, its positional gradient and its cost.
-// pcol = this lane's column of a [15][64] pass buffer (stash around the manipulator block, which needs the registers).
 // Shared by the one-wave and the several-waves evaluation: same arithmetic, same bits.
+//
+// Stage 2 is two functions around the call of the block, sample_mani() and sample_rest(): the caller forms the sample's
+// geometry (piece, sample index, step, position) from the lane number before the call and AGAIN after it -- everything a
+// lane holds in registers across the call is saved to and restored from scratch memory, so nothing but the loop's own
+// state is kept (round 4: ~20 dwords of loop state and the 12-double return value per pass; rounds 1-3 parked 14 doubles per
+// lane in an LDS pass buffer).  Every sum is formed in the order of before.
 // ---------------------------------------------------------------------------------------------
-template <int STAGE, int OCC>
-__device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, int i, int j, int e, bool act, double step, double half,
-                                            double posx, double posy, const TOPAY_GLB DevMap* mp, double wM, double wA,
-                                            double wD, double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
-  const DevParams& P = g_P;
-  (void)C;
-  // Stage 2 starts with the manipulator block: it only needs the pose (theta, joints) of the sample, and everything else
-  // of the body is computed AFTER the call from the coefficients in LDS -- nothing of the sample has to be parked while
-  // the block owns the registers (rounds 1-3 parked 14 doubles per lane in an LDS pass buffer, 7.7 KB per wave, the
-  // largest single block of the LDS plan).  Every sum is formed in the order of before.
+template <int OCC>
+__device__ __forceinline__ ManiOut sample_mani(lds_cdp cL, int rows, int i, int j, int e, bool act, double step, double half, double posx,
+                                               double posy, const TOPAY_GLB DevMap* mp, glb_dp mstash, lds_dp mg_lds) {
   ManiOut mo_;
-  if (STAGE == 2) {
-    ManiInA minA_;
-    ManiInB minB_;
-    {
-      const double s1 = j * half;
-      const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
-      double pv[9];
-#pragma unroll
-      for (int d = 0; d < 9; d++) {
-        if (d == 1) continue;   // (the arc length is not part of the pose)
-        lds_cdp c = cL + d * rows + 6 * i;
-        pv[d] = fma(c[5], s5, fma(c[4], s4, fma(c[3], s3, fma(c[2], s2, fma(c[1], s1, c[0])))));
-      }
-      minA_.pos[0] = posx; minA_.pos[1] = posy; minA_.pos[2] = pv[0];
-#pragma unroll
-      for (int q = 0; q < 5; q++) minA_.pos[3 + q] = pv[2 + q];
-      minB_.pos8 = pv[7]; minB_.pos9 = pv[8];
-      det_sincos(pv[0], &minB_.sth, &minB_.cth);
-    }
-    minB_.omg = (j == 0 || j == 2 * TOPAY_K) ? 0.5 : 1.0;
-    minB_.step = step;
-    const glb_dp stash_ = act ? C.mstash + 36 * e : (glb_dp)nullptr;
-#ifdef TOPAY_STAMPS
-    const long long mt0_ = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    // The call sits in a block of its own, entered by a SCALAR branch the compiler cannot fold: the register allocator
-    // parks what is live across the call at the top of the call's block, and when that block is the join of a divergent
-    // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (docs/EXPERIMENTS.md, "The hardware-only failures";
-    // tools/isa_lint.py found it again in round 4 when the callee's smaller register need changed the caller's allocation).
-    if (topay_opaque_true()) mo_ = manipulator_block<OCC>(mp, minA_, minB_, stash_);
-#ifdef TOPAY_STAMPS
-    if (C.stamps && C.lane == 0) C.stamps[13] += (long long)__builtin_amdgcn_s_memtime() - mt0_;
-#endif
-    // Everything below is computed from (i, j, half) again: made opaque here, or the compiler keeps the coefficient
-    // addresses and the powers of the local time it formed for the pose alive across the call -- in scratch memory,
-    // saved and restored once per pass -- to spare a dozen integer additions and multiplications.
-    TOPAY_OPAQUE_I(i);
-    TOPAY_OPAQUE_I(j);
-    TOPAY_OPAQUE(half);
-  }
-  // (the outputs are zeroed here, after the call: zeros formed by the caller before it were saved and restored around it)
+  // The call sits in a block of its own, entered by a SCALAR branch the compiler cannot fold: the register allocator
+  // parks what is live across the call at the top of the call's block, and when that block is the join of a divergent
+  // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (docs/EXPERIMENTS.md, "The hardware-only failures";
+  // tools/isa_lint.py found it again in round 4 when the callee's smaller register need changed the caller's allocation).
+  if (topay_opaque_true()) mo_ = manipulator_block<OCC>(mp, cL, rows, i, j, half, step, posx, posy, act ? e : -1, mstash, mg_lds);
+  return mo_;
+}
+
+template <int STAGE>
+__device__ __forceinline__ void sample_rest(lds_cdp cL, int rows, int i, int j, double step, double half, double posx, double posy,
+                                            const TOPAY_GLB DevMap* mp, double wM, double wA, double wD, const ManiOut& mo_, lds_cdp mg_lds,
+                                            double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
+  const DevParams& P = g_P;
 #pragma unroll
   for (int v = 0; v < 12; v++) gB[v] = 0.0;
   gdTs = 0.0; gpx = 0.0; gpy = 0.0;
@@ -1158,7 +1181,6 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
     }
     // joint velocity / acceleration limits — moma_traj_opt.cpp:1674-1710 (cost and gdT here; the rare gradBeta rows are
     // produced in the follow-up round of the gradient phase when any lane is active), and moma_grad.tail(7) . dq
-    const double* mg = mo_.g;
     double qacc = 0.0;
 #pragma unroll
     for (int q = 0; q < 7; q++) {
@@ -1180,17 +1202,18 @@ __device__ __forceinline__ void sample_body(EvalCtx& C, lds_cdp cL, int rows, in
         cst += omg * step * P.s2_mani_acc_weight * pe;
         jva = true;
       }
-      gB[5 + q] = mg[3 + q];            // gradBeta row 0 of the joints (1671)
-      qacc += mg[3 + q] * a1;
+      const double mgq = mg_lds[q * 64];   // the block's d/dq_q, from the lane's column of the pass buffer
+      gB[5 + q] = mgq;                     // gradBeta row 0 of the joints (1671)
+      qacc += mgq * a1;
       TOPAY_SCHED_FENCE();
     }
     cst = cst + mo_.cost;
     gdTs = gdTs + mo_.gdT;
-    gpx += mg[0];
-    gpy += mg[1];
-    gB[0] = mg[2];                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
-    gdTs += mg[2] * th1 * real_alpha;   // (1670)
-    gdTs += qacc * real_alpha;          // (1672)
+    gpx += mo_.gx;
+    gpy += mo_.gy;
+    gB[0] = mo_.gth;                      // gdC(:, theta) += beta0 * moma_grad(2)   (1669)
+    gdTs += mo_.gth * th1 * real_alpha;   // (1670)
+    gdTs += qacc * real_alpha;            // (1672)
   }
 }
 

@@ -264,7 +264,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
 // The evaluation, NW waves.  RMAX = system rows per thread (rows <= 64 NW RMAX), N <= 64 NW.
 // ---------------------------------------------------------------------------------------------
 template <int STAGE, int RMAX, int NW, int OCC = 1>
-__device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
+__device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB DevMap* mp, const GradGate gate) {
   constexpr int NT = 64 * NW;
   // (wave-uniform context fields into scalar registers: what stays in vector registers is saved and restored around every
   // call of the manipulator block)
@@ -290,13 +290,22 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   const glb_dp c_coefg = uniform_ptr(C.coefg);
 
   const DevParams& P = g_P;
-  const int lane = C.lane, tid = C.tid, wave = __builtin_amdgcn_readfirstlane(C.wave);
+  // (lane and tid are formed again after every call of the manipulator block -- fresh_lane_id -- instead of being kept
+  // across it: what a lane holds in vector registers across the call goes through scratch memory)
+  int lane = C.lane, tid = C.tid;
+  const int wave = __builtin_amdgcn_readfirstlane(C.wave);
   const int N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_cdp cL = uniform_ptr(C.cL);
   const glb_dp c_sbuf = uniform_ptr(C.sbuf);
+  const glb_dp c_mstash = uniform_ptr(C.mstash);
   const int c_sbs = __builtin_amdgcn_readfirstlane(C.sb_stride);
   const double g_skip_thr = uniform_f64(gate.skip_thr);
   const bool g_early_ok = __builtin_amdgcn_readfirstlane(gate.early_ok ? 1 : 0) != 0;
+  GradGate ugate;   // the line search's gate in scalar registers (it is consulted after the sample passes)
+  ugate.always = __builtin_amdgcn_readfirstlane(gate.always ? 1 : 0) != 0;
+  ugate.has_early = __builtin_amdgcn_readfirstlane(gate.has_early ? 1 : 0) != 0;
+  ugate.finit = uniform_f64(gate.finit); ugate.thr = uniform_f64(gate.thr); ugate.early = uniform_f64(gate.early);
+  ugate.early_ok = g_early_ok; ugate.skip_thr = g_skip_thr;
   int rp = 0;                                  // phase of the workgroup-reduction scratch
   const int npl = __builtin_amdgcn_readfirstlane(C.npass_lds);
   constexpr int RD = NW > 1 ? 8 : 0;           // (one wave: the reductions need no LDS)
@@ -306,10 +315,9 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   constexpr int PBR = NW == 1 ? 7 : 14;        // rows of a wave's pass buffer
   minco_generate_mw<NW, OCC>(C);
 
-  // ---- jerk energy & dJ/dT per piece (thread <-> piece; N <= NT)
-  double jerk_gdT = 0.0, jerk_e = 0.0;
-  if (tid < N) {
-    const int i = tid;
+  // ---- jerk energy per piece (thread <-> piece; N <= NT); its dJ/dT part is formed in the gradient phase, from the same
+  // expressions (it would otherwise be carried in a register across every call of the manipulator block)
+  auto jerk_terms = [&](int i, double& e_out, double& gdT_out) __attribute__((always_inline)) {
     double w33 = 0, w43 = 0, w44 = 0, w53 = 0, w54 = 0, w55 = 0;
 #pragma unroll
     for (int d = 0; d < 9; d++) {
@@ -319,21 +327,15 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
       w53 += (c5 * e) * c3; w54 += (c5 * e) * c4; w55 += (c5 * e) * c5;
     }
     const double T1 = c_Tp[i], T2 = c_Tp[N + i], T3 = c_Tp[2 * N + i], T4 = c_Tp[3 * N + i], T5 = c_Tp[4 * N + i];
-    jerk_e = 36.0 * w33 * T1 + 144.0 * w43 * T2 + 192.0 * w44 * T3 + 240.0 * w53 * T3 + 720.0 * w54 * T4 + 720.0 * w55 * T5;
-    jerk_gdT = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
+    e_out = 36.0 * w33 * T1 + 144.0 * w43 * T2 + 192.0 * w44 * T3 + 240.0 * w53 * T3 + 720.0 * w54 * T4 + 720.0 * w55 * T5;
+    gdT_out = 36.0 * w33 + 288.0 * w43 * T1 + 576.0 * w44 * T2 + 720.0 * w53 * T2 + 2880.0 * w54 * T3 + 3600.0 * w55 * T4;
+  };
+  double jerk_e = 0.0;
+  if (tid < N) {
+    double unused_;
+    jerk_terms(tid, jerk_e, unused_);
   }
   const double jerk_cost = wg_sum<NW>(c_red, rp, wave, jerk_e);
-
-  // ---- row bookkeeping: thread tid owns the system rows tid + NT r
-  int rrow[RMAX], rpiece[RMAX], rk[RMAX];
-  bool ract[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; r++) {
-    rrow[r] = tid + NT * r;
-    ract[r] = rrow[r] < rows;
-    rpiece[r] = rrow[r] / 6;
-    rk[r] = rrow[r] - 6 * rpiece[r];
-  }
 
   lds_dp gxy = c_X;                             // [13N][2] XY prefix of each even sample, then its positional gradient
   lds_dp pball = c_X + 26 * N;                  // [NW][PBR][64] one pass buffer per wave
@@ -391,7 +393,7 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
   wg_barrier<NW>();
 
   // =========================== sweep 1, phase B: sample bodies, one pass per wave and round
-  double carryx = 0.0, carryy = 0.0;   // XY prefix carried across passes: the totals of the passes before `pc`, added in order
+  double carryx = 0.0, carryy = 0.0;   // XY prefix carried across passes: the totals of the passes before `pc`, added in order (scalar registers)
   int pc = 0;
   double cost_pen = 0.0;               // per-lane penalty cost in the one-wave order: lane l adds its sample of pass 0, 1, 2, ...
   for (int k = 0; k < nround; k++) {
@@ -399,46 +401,58 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     double cst_out = 0.0;
     if (pass < npass) {
       while (pc < pass) {
-        carryx += ptot[2 * pc];
-        carryy += ptot[2 * pc + 1];
+        carryx = uniform_f64(carryx + ptot[2 * pc]);
+        carryy = uniform_f64(carryy + ptot[2 * pc + 1]);
         pc++;
       }
-      const int e = pass * 64 + lane;
-      const bool act = e < NE;
-      const int i = act ? e / TOPAY_EP : N - 1;
-      const int m = act ? e - TOPAY_EP * i : 0;
-      const int j = 2 * m;
-      const double T1 = c_Tp[i];
-      const double step = T1 / TOPAY_K, half = step / 2.0;
-      const double px0 = act ? gxy[2 * e] : 0.0, py0 = act ? gxy[2 * e + 1] : 0.0;
-      const double posx = c_sx + (carryx + px0);
-      const double posy = c_sy + (carryy + py0);
+      // the sample of lane ln in this pass: index, piece, step, XY position (prefix inside the pass + carry)
+      int e, i, m, j;
+      bool act;
+      double step, half, posx, posy;
+      auto geometry = [&](int ln) __attribute__((always_inline)) {
+        e = pass * 64 + ln;
+        act = e < NE;
+        i = act ? e / TOPAY_EP : N - 1;
+        m = act ? e - TOPAY_EP * i : 0;
+        j = 2 * m;
+        const double T1 = c_Tp[i];
+        step = T1 / TOPAY_K;
+        half = step / 2.0;
+        const double px0 = act ? gxy[2 * e] : 0.0, py0 = act ? gxy[2 * e + 1] : 0.0;
+        posx = c_sx + (carryx + px0);
+        posy = c_sy + (carryy + py0);
+      };
+      geometry(lane);
       if (act && m == TOPAY_K) {
         c_pcs[2 * N + 2 * (i + 1)] = posx;
         c_pcs[2 * N + 2 * (i + 1) + 1] = posy;
       }
-      double gB[12];
-#pragma unroll
-      for (int v = 0; v < 12; v++) gB[v] = 0.0;
-      double gdTs = 0.0, gpx = 0.0, gpy = 0.0;
-      bool jva = false;
       if (!skip_body) {   // (wave-uniform: no call of the non-inlined manipulator block under a partial EXEC mask, see topay_eval.h)
-        double cst;
-        sample_body<STAGE, OCC>(C, cL, rows, i, j, e, act, step, half, posx, posy, mp, wM, wA, wD, gB, gdTs, gpx, gpy, jva, cst);
-        if (act) cst_out = cst;
-      }
-      if (act && !skip_body) {
-        gxy[2 * e] = gpx;
-        gxy[2 * e + 1] = gpy;
-        glb_dp sb = c_sbuf + e;
-        const int ss = c_sbs;
-#pragma unroll
-        for (int v = 0; v < 5; v++) sb[v * ss] = gB[v];
-        sb[5 * ss] = gdTs;
+        ManiOut mo;
+        mo.gx = mo.gy = mo.gth = mo.cost = mo.gdT = 0.0;
         if (STAGE == 2) {
+          mo = sample_mani<OCC>(cL, rows, i, j, e, act, step, half, posx, posy, mp, c_mstash, pbuf + lane);
+          lane = fresh_lane_id(lane);
+          tid = wave * 64 + lane;
+          geometry(lane);
+        }
+        double gB[12], gdTs, gpx, gpy, cst;
+        bool jva;
+        sample_rest<STAGE>(cL, rows, i, j, step, half, posx, posy, mp, wM, wA, wD, mo, pbuf + lane, gB, gdTs, gpx, gpy, jva, cst);
+        if (act) {
+          cst_out = cst;
+          gxy[2 * e] = gpx;
+          gxy[2 * e + 1] = gpy;
+          glb_dp sb = c_sbuf + e;
+          const int ss = c_sbs;
 #pragma unroll
-          for (int v = 0; v < 7; v++) sb[(6 + v) * ss] = gB[5 + v];
-          sb[13 * ss] = jva ? 1.0 : 0.0;
+          for (int v = 0; v < 5; v++) sb[v * ss] = gB[v];
+          sb[5 * ss] = gdTs;
+          if (STAGE == 2) {
+#pragma unroll
+            for (int v = 0; v < 7; v++) sb[(6 + v) * ss] = gB[5 + v];
+            sb[13 * ss] = jva ? 1.0 : 0.0;
+          }
         }
       }
     }
@@ -465,8 +479,8 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
     }
   }
   while (pc < npass) {
-    carryx += ptot[2 * pc];
-    carryy += ptot[2 * pc + 1];
+    carryx = uniform_f64(carryx + ptot[2 * pc]);
+    carryy = uniform_f64(carryy + ptot[2 * pc + 1]);
     pc++;
   }
   if (NW == 1) lds_sync();   // (several waves: the barrier of the last round's cost exchange) piece-end positions are read below
@@ -520,9 +534,24 @@ __device__ __noinline__ double eval_cost_grad_mw(EvalCtx& C, const TOPAY_GLB Dev
 
   STAMP(C, 5);  // per-piece terms, cost
   if (skip_body) return f_skip;
-  if (!gate.needs(f_total)) return f_total;
+  if (!ugate.needs(f_total)) return f_total;
 
   // =========================== gradient phase ===========================
+  // ---- row bookkeeping: thread tid owns the system rows tid + NT r (formed here, after the sample passes)
+  int rrow[RMAX], rpiece[RMAX], rk[RMAX];
+  bool ract[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    rrow[r] = tid + NT * r;
+    ract[r] = rrow[r] < rows;
+    rpiece[r] = rrow[r] / 6;
+    rk[r] = rrow[r] - 6 * rpiece[r];
+  }
+  double jerk_gdT = 0.0;
+  if (tid < N) {
+    double unused_;
+    jerk_terms(tid, unused_, jerk_gdT);
+  }
   // dJ/dC accumulator of this thread's rows (registers): theta, s, seven joints
   double a0[RMAX], a1[RMAX], aq[RMAX][7];
   double rbh[RMAX][3];   // hs-powers of each row (basis_k(k, hs))

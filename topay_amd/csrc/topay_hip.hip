@@ -122,11 +122,18 @@ static const int kBigFirst = 4;   // the classes of long candidates (N > 32) sta
 typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
 typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
 struct ClassDef {
-  int max_n, rmax, nw;
+  int max_n, rmax, nw;   // rows per thread and waves of an EVALUATION of the class (= threads of its workgroups / 64)
   solve_kernel_t solve;
   eval_kernel_t eval;
   int occ = 2;   // waves per SIMD the kernel is built for (512 / occ registers per lane; every kernel: 256, no AGPRs)
   solve_kernel_t lat = nullptr;   // helper-wave kernel of a one-wave class (topay_set_latency_mode): 4 waves per workgroup
+  // The waves the SOLVER's vectors are divided over and its rows per lane (elements per thread / 2): what the bits of a solve
+  // depend on (topay_class_of).  0 = as the evaluation.  The long classes run a one-wave solver on wave 0 of a four-wave
+  // workgroup whose other waves join the evaluations only (helper waves, topay_solve.h): solver_nw 1, helpers true.
+  int solver_nw = 0, solver_rmax = 0;
+  bool helpers = false;           // `solve` is a helper-wave kernel: its LDS carries the command block
+  int snw() const { return solver_nw ? solver_nw : nw; }
+  int srmax() const { return solver_rmax ? solver_rmax : rmax; }
 };
 static const int kLatWaves = 4;
 static const ClassDef* class_table() {
@@ -134,13 +141,17 @@ static const ClassDef* class_table() {
     static ClassDef t[TOPAY_NBUCKET] = {
         {10, 1, 1, k_solve1, k_eval1, 2, k_lat1}, {15, 2, 1, k_solve2, k_eval2, 2, k_lat2}, {21, 2, 1, k_solve2, k_eval2, 2, k_lat2},
         {32, 3, 1, k_solve3, k_eval3, 2, k_lat3},
-        {42, 2, 4, k_solve2w4, k_eval2w4, 2}, {64, 2, 4, k_solve2w4, k_eval2w4, 2}, {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2}};
+        {42, 2, 4, k_long5, k_eval2w4, 2, nullptr, 1, 5, true}, {64, 2, 4, k_long5, k_eval2w4, 2, nullptr, 1, 5, true},
+        {TOPAY_MAX_N, 3, 4, k_long10, k_eval3w4, 2, nullptr, 1, 10, true}};
     // Four waves per trajectory for N = 33..64 since round 4.  Round 3 (one wave per SIMD), one / two / four waves for both
     // classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 / 1.03 s -- four waves halve a long
     // candidate's solve but held four SIMDs for it.  With two waves per SIMD a wave holds half a SIMD, the common classes
     // got faster and the long candidates set the length of a batch again (their launch was the longest of a serial step,
     // 1.06-1.21 s): two / four waves for N = 43..64 now give 11.5-11.6k / 11.8-11.9k and serial steps of 1.07 / 0.95 s, four
     // for N = 33..42 as well 0.94 s (tools/experiments/r4_mw.sh).
+    // Round 5: the SOLVER of the long classes runs on one wave (k_long5 / k_long10: 10 / 20 vector elements per lane) and only
+    // the evaluations use the four waves -- every reduction of the four-wave solver (two per history pair of the two-loop
+    // recursion) was a workgroup reduction through LDS and a barrier (k_solve2w4: VALU active 18.7 % of its wave cycles).
 #ifdef TOPAY_EXPERIMENTS
     auto env_nw = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     const int w4 = env_nw("TOPAY_MW_C4", 4), w5 = env_nw("TOPAY_MW_C5", 4);
@@ -148,6 +159,14 @@ static const ClassDef* class_table() {
     else if (w4 == 2) t[4] = {42, 2, 2, k_solve2w2, k_eval2w2, 2};
     if (w5 == 1) t[5] = {64, 6, 1, k_solve6, k_eval6, 2};
     else if (w5 == 2) t[5] = {64, 3, 2, k_solve3w2, k_eval3w2, 2};
+    // TOPAY_LONG_SOLVER=4: the four-wave solver of round 4 for the long classes (A/B)
+    if (const char* e = getenv("TOPAY_LONG_SOLVER")) {
+      if (atoi(e) == 4) {
+        if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 2};
+        if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 2};
+        t[6] = {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2};
+      }
+    }
 #endif
     return t;
   }();
@@ -166,7 +185,8 @@ static size_t class_lds_bytes(const ClassDef& cd, int nm) {
       if (q) q++;
     }
   }
-  return (size_t)(d + 8 + 40) * sizeof(double);   // + past-cost ring [8] + the solver state parked across an evaluation [40]
+  // + past-cost ring [8] + the solver state parked across an evaluation [40] (+ the command block of a helper-wave kernel)
+  return (size_t)(d + 8 + 40 + (cd.helpers ? TOPAY_CMD_DOUBLES : 0)) * sizeof(double);
 }
 
 // Runs when the library is loaded: effective if the HIP runtime has not been initialised yet in this process
@@ -1185,7 +1205,7 @@ static hipError_t set_kernel_attributes(int device) {
 static int steal_floor(int k) {
   const ClassDef* ct = class_table();
   int lo = k;
-  while (lo > 0 && ct[lo - 1].nw == ct[k].nw && ((lo - 1 >= kBigFirst) == (k >= kBigFirst))) lo--;
+  while (lo > 0 && ct[lo - 1].nw == ct[k].nw && ct[lo - 1].snw() == ct[k].snw() && ((lo - 1 >= kBigFirst) == (k >= kBigFirst))) lo--;
   return lo;
 }
 
@@ -2484,8 +2504,8 @@ topay_status topay_class_of(int n_pieces, int* waves, int* elements_per_thread, 
   if (n_pieces <= 0 || n_pieces > TOPAY_MAX_N) return TOPAY_ERR_TOO_MANY_PIECES;
   const int k = bucket_of(n_pieces);
   const ClassDef& cd = class_table()[k];
-  if (waves) *waves = cd.nw;
-  if (elements_per_thread) *elements_per_thread = 2 * cd.rmax;
+  if (waves) *waves = cd.snw();
+  if (elements_per_thread) *elements_per_thread = 2 * cd.srmax();
   if (class_index) *class_index = k;
   return TOPAY_OK;
 }

@@ -347,8 +347,10 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, 2)
-TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
-TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, 2)
+// the long classes (N = 33..64 / 65..128): one-wave solver with 10 / 20 vector elements per lane on wave 0, evaluations on
+// four waves with 2 / 3 system rows per thread
+TOPAY_LATENCY_KERNEL(k_long5, 5, 2, 4, 2)
+TOPAY_LATENCY_KERNEL(k_long10, 10, 3, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat1, 1, 1, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat2, 2, 1, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat3, 3, 1, 4, 2)
@@ -366,6 +368,8 @@ TOPAY_EVAL_KERNEL(k_eval2w4, 2, 4, 2)
 #ifdef TOPAY_EXPERIMENTS
 // A/B variants (tools/ab_lib.sh builds with -DTOPAY_EXPERIMENTS): the one-wave kernels of the long classes and four waves
 // for N <= 64
+TOPAY_SOLVE_KERNEL(k_solve2w4, 2, 4, 2)
+TOPAY_SOLVE_KERNEL(k_solve3w4, 3, 4, 2)
 TOPAY_SOLVE_KERNEL(k_solve4, 4, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve6, 6, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve2w2, 2, 2, 2)
