@@ -65,3 +65,37 @@ def serpentine_path(total_len, step=1.3, row=17.0, dy=1.0):
         q = np.linspace(0.2, -0.3, 7) * (k / max(1, len(pts) - 1))
         states.append(np.concatenate([p, [th], q]))
     return np.array(states)
+
+
+AGREEMENT_GOLDEN = os.path.join(ROOT, "tests", "golden", "agreement_stats.json")
+
+
+def track_agreement(name, values, band=0.05):
+    """Agreement figures of the device against the oracle at convergence (fractions in [0, 1]: same local minimum, same
+    winner, Kolmogorov-Smirnov distance ...).  Converged values cannot be compared one by one (the reference's iteration
+    amplifies rounding), so these statistics are what a regression of the converged behaviour would
+    move: they are compared with the figures committed in tests/golden/agreement_stats.json within +-band, and what this
+    run measured is written to gpurun_out/agreement_stats_measured.json (merged per test name), from where a deliberate
+    change of the arithmetic -- which moves the convergence paths -- is taken over into the golden file by hand."""
+    import json
+
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "agreement_stats_measured.json")
+    try:
+        with open(path) as f:
+            allm = json.load(f)
+    except (OSError, ValueError):
+        allm = {}
+    allm[name] = {k: float(v) for k, v in values.items()}
+    with open(path, "w") as f:
+        json.dump(allm, f, indent=1, sort_keys=True)
+    try:
+        with open(AGREEMENT_GOLDEN) as f:
+            gold = json.load(f)
+    except OSError:
+        gold = {}
+    assert name in gold, f"no committed agreement figures for {name}: measured {allm[name]}"
+    for k, g in gold[name].items():
+        assert k in values, (name, k)
+        assert abs(float(values[k]) - g) <= band, f"{name}.{k}: measured {float(values[k]):.4f}, committed {g:.4f} (band {band})"

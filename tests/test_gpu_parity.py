@@ -343,6 +343,9 @@ def test_config2_tables_64_candidates():
         o.optimize()
         ref.append(settles(path, o.get_x(), o.alm_state(), o.traj_cost()))
     assert np.mean(dev) >= np.mean(ref) - 0.15 and np.mean(dev) > 0.4, (np.mean(dev), np.mean(ref))
+    from conftest import track_agreement
+    track_agreement("config2_64_candidates", dict(success_dev=ok.mean(), success_ref=r["success"].mean(), same_minimum=same.mean(),
+                                                  settles_dev=np.mean(dev), settles_ref=np.mean(ref)), band=0.08)
 
 
 def test_converged_solves_equal_oracle_solver_in_device_order():

@@ -172,6 +172,11 @@ def test_benchmark_slice_statistics_match_the_oracle():
     assert solved_same > 0.95 and abs(len(wd) - len(wr)) <= 0.03 * S
     assert abs(np.median(dur_ratio) - 1.0) < 0.01 and np.mean(np.abs(dur_ratio - 1) < 0.05) > 0.8
     assert same_winner > 0.4
+    # ... and against the figures of the committed build: a regression that halves the agreement fails here
+    from conftest import track_agreement
+    track_agreement("benchmark_slice", dict(success_dev=ok.mean(), success_ref=ro.mean(), accepted_dev=acc_dev.mean(), same_success_verdict=np.mean(ok == ro),
+                                            stage1_counters_equal=s1_same, same_minimum=same_min, ks_distance=ks, same_winner=same_winner,
+                                            scenarios_solved_same=solved_same, winner_duration_within_5pct=np.mean(np.abs(dur_ratio - 1) < 0.05)))
     tb.close()
 
 
