@@ -35,6 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+# A sample pass with n < 64 active lanes is cheaper than a full one -- its gathers and its penalty branches scale with the
+# lanes that are there.  Measured on the evaluation kernel alone (tools/gpu_eval_by_n.py, round 5: N = 4..16, 2048 candidates
+# each): cost(n) / cost(64) = 0.42 + 0.58 n / 64.  Feeds lane_utilisation_effective.
+PASS_COST_FIXED = 0.42
 
 
 def algorithmic_bytes(stats, n_pieces):
@@ -400,12 +404,28 @@ def main():
     # Launch duration for the roofline: HIP events on the launch stream bracket each step's solve; with steps
     # overlapping, those spans overlap too, so the average wall time per step is used instead (never smaller than the
     # true per-launch cost).
-    kms = float(np.mean(kernel_ms)) if depth == 1 else elapsed / args.steps * 1e3
-    achieved = abytes / (kms * 1e-3) / 1e9
+    kms_wall = float(np.mean(kernel_ms)) if depth == 1 else elapsed / args.steps * 1e3
+    sustained = abytes / (kms_wall * 1e-3) / 1e9
     if serial is not None:
         serial["trajectories_per_s_per_gpu"] = (B - n_not_launched) / (serial["ms_per_step"] * 1e-3)
         serial["achieved_GBps"] = abytes / (serial["kernel_ms"] * 1e-3) / 1e9
         serial["frac"] = serial["achieved_GBps"] / HBM_PEAK_GBS
+    # The roofline figure proper is PER LAUNCH: the algorithmic bytes of one step over the HIP-event span of its launches when
+    # steps do not overlap (the serial steps run right after the timed region; with --inflight 1 the timed steps themselves).
+    # With batches in flight the launches of consecutive steps overlap and wall time per step is shorter than any launch:
+    # that quotient is the sustained rate of the device, reported beside it, never as `achieved`.
+    if depth == 1:
+        kms, kdef = kms_wall, "mean HIP-event span of the batch's concurrent launches (timed steps, one batch in flight)"
+    elif serial is not None:
+        kms, kdef = serial["kernel_ms"], ("mean HIP-event span of the batch's concurrent launches over the strictly serial steps run after the timed "
+                                          "region (serial_steps); the timed region overlaps three batches -- see `sustained`")
+    else:
+        kms, kdef = kms_wall, "NO serial steps in this run (--no-serial): wall time of the timed region / steps, i.e. the sustained figure"
+    achieved = abytes / (kms * 1e-3) / 1e9
+    # the same with the measured cost of a partly filled pass instead of a whole pass for every pass (PASS_COST_FIXED)
+    tail_ = 13.0 * np_ - 64.0 * (np.ceil(13.0 * np_ / 64.0) - 1.0)
+    eff_passes = (np.ceil(13.0 * np_ / 64.0) - 1.0) + (PASS_COST_FIXED + (1.0 - PASS_COST_FIXED) * tail_ / 64.0)
+    lane_util_eff = float((ev_ * 13.0 * np_).sum() / max(1.0, (ev_ * 64.0 * eff_passes).sum()))
     # HBM-side bytes of one step from the committed PMC passes of this same command (tools/profile_round.sh; FETCH_SIZE
     # and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected live here).  Only quoted when the
     # workload is the one that was profiled.
@@ -466,7 +486,7 @@ def main():
             "accepted_trajectories_per_s": float((ok & gate).sum() / max(1, B - n_not_launched) * total_traj * args.steps / elapsed),
             # samples evaluated per sample slot of the 64-lane passes (13 N samples in ceil(13 N / 64) passes), weighted by
             # every candidate's evaluations: every multiple of five pieces pays a whole pass for N / 5 samples
-            "lane_utilisation_sweeps": lane_util,
+            "lane_utilisation_sweeps": lane_util, "lane_utilisation_effective": lane_util_eff,
             "mean_evals_per_traj": float((stats[:, 2] + stats[:, 5]).mean()),
             "mean_iters_per_traj": float((stats[:, 1] + stats[:, 4]).mean()),
             "max_evals_per_traj": int((stats[:, 2] + stats[:, 5]).max()),
@@ -490,12 +510,12 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3 + k_solve2w4/3w4 (persistent solve: one workgroup of 1 or 4 waves per trajectory takes candidates from its class's queue; the "
-                      "up to six class launches of a batch run concurrently)",
+            "kernel": "k_solve1/2/3 + k_long5/10 (persistent solve: one workgroup of 1 or 4 waves per trajectory takes candidates from its class's queue; the "
+                      "up to six class launches of a batch run concurrently; the long classes solve on one wave and evaluate on four)",
             "kernel_ms": kms,
-            "kernel_ms_definition": ("mean HIP-event span of the batch's concurrent launches" if depth == 1 else
-                                     "wall time of the timed region / steps (launches of consecutive steps overlap; the event span of each "
-                                     "is in kernel_span_ms_each, the non-overlapping figures in serial_steps)"),
+            "kernel_ms_definition": kdef,
+            "sustained": {"achieved": sustained, "frac": sustained / HBM_PEAK_GBS, "ms_per_step": kms_wall,
+                          "definition": "algorithmic bytes per step over the wall time of the timed region per step (batches in flight overlap)"},
             "kernel_span_ms_each": [float(k) for k in kernel_ms], "steps_in_flight": depth,
             "serial_steps": serial,
             "algorithmic_bytes_per_step": abytes,

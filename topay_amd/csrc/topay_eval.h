@@ -1048,270 +1048,6 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
   return out;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The manipulator block for a SHORT pass (round 5): the last sample pass of a candidate holds 13 N mod 64 samples -- one
-// for N = 5, two for N = 10, fifteen for N = 11 -- and a call of the block costs the same whatever the number of active
-// lanes (lane_utilisation_sweeps 0.80 on the benchmark batch).  With at most 32 (16) samples in the pass the 12 spheres
-// of a sample are divided over G = 2 (4) lane groups of 64 / G lanes: lane l works on sample l mod (64 / G) and on
-// the spheres [12 g / G, 12 (g + 1) / G) of it, g = l / (64 / G).  Every group runs the cheap part for itself -- pose, the
-// eight sines and cosines, the chain walk that places the 12 centres, the screening of the 55 sphere pairs -- then takes
-// the ESDF lookups, penalties and arm-local forces of ITS spheres only, walks the chain for the joint torques with the
-// other spheres' forces at zero (the torques are linear in the forces), and the groups' partial results -- base wrench,
-// seven torques, cost, dJ/dT part -- are added across the groups in a fixed order, (g0 + g1) + (g2 + g3); every lane ends
-// with the totals.  Joint limits are per sample and added afterwards.
-//   A sample whose arm collides with itself (fewer than one in a thousand) is not handled here: the function reports
-// it (fallback) and the caller runs the whole pass through manipulator_block instead.
-//   The sums are formed in another order than manipulator_block's (sphere order there, per group and then across the
-// groups here): the results differ in the last bits.  Which of the two a sample goes through depends only on its
-// candidate's number of pieces, so a candidate's evaluation is the same on every run, for every number of waves, and in
-// the lane emulator; against the oracle the per-evaluation tolerance (1e-11) holds as before.
-// ---------------------------------------------------------------------------------------------
-struct ManiOutSplit {
-  ManiOut o;
-  int fallback;
-};
-template <int G>
-__device__ __forceinline__ double group_select(int g, const double* v, int j) {
-  constexpr int SPG = TOPAY_NSPH / G;
-  if (G == 2) return g == 0 ? v[j] : v[SPG + j];
-  const double lo = (g & 1) ? v[SPG + j] : v[j], hi = (g & 1) ? v[3 * SPG + j] : v[2 * SPG + j];
-  return (g & 2) ? hi : lo;
-}
-template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-  if (G == 4) v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-template <int OCC, int G>
-__device__ __noinline__ ManiOutSplit manipulator_block_split(const TOPAY_GLB DevMap* mp, lds_cdp cL, int rows, int pi, int pj, double half, double step,
-                                                             double posx, double posy, int lane, lds_dp mg_lds) {
-  static_assert(G == 2 || G == 4, "lane groups");
-  constexpr int SPG = TOPAY_NSPH / G;   // spheres per group
-  const DevParams& P = g_P;
-  const DevMap M = load_map(mp);
-  const int g = lane / (64 / G);
-  double pos[10];
-  pos[0] = posx; pos[1] = posy;
-  double sth, cth;
-  {
-    const double s1 = pj * half;
-    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s3 * s2;
-#pragma unroll
-    for (int d = 0; d < 9; d++) {
-      if (d == 1) continue;
-      lds_cdp c = cL + d * rows + 6 * pi;
-      pos[d == 0 ? 2 : d + 1] = fma(c[5], s5, fma(c[4], s4, fma(c[3], s3, fma(c[2], s2, fma(c[1], s1, c[0])))));
-    }
-    det_sincos(pos[2], &sth, &cth);
-  }
-  const double omg = (pj == 0 || pj == 2 * TOPAY_K) ? 0.5 : 1.0;
-  const double mu = P.relu_mu;
-  const double w = omg * step;
-  double sq[7], cq[7];
-#pragma unroll
-  for (int i = 0; i < 7; i++) det_sincos(pos[3 + i], &sq[i], &cq[i]);
-  double A[9];
-  {
-    const double Rz[9] = {cth, -sth, 0.0, sth, cth, 0.0, 0.0, 0.0, 1.0};
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++)
-        A[a * 3 + b] = Rz[a * 3 + 0] * P.relR[0 * 3 + b] + Rz[a * 3 + 1] * P.relR[1 * 3 + b] + Rz[a * 3 + 2] * P.relR[2 * 3 + b];
-  }
-  const double p0x = pos[0] + (cth * P.relT[0] - sth * P.relT[1]);
-  const double p0y = pos[1] + (sth * P.relT[0] + cth * P.relT[1]);
-  const double p0z = P.p0z;
-  // walk 1: all 12 centres (the pair screening needs them), then this group's own
-  double mx[SPG], my[SPG], mz[SPG];
-  bool collides;
-  {
-    double Px[TOPAY_NSPH], Py[TOPAY_NSPH], Pz[TOPAY_NSPH];
-    double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-    int sidx = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int cnt = (i % 2 == 0) ? 2 : 1;
-#pragma unroll
-      for (int c = 0; c < cnt; c++) {
-        const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
-        Px[sidx] = p0x + fma(A[2], lz, fma(A[1], ly, A[0] * lx));
-        Py[sidx] = p0y + fma(A[5], lz, fma(A[4], ly, A[3] * lx));
-        Pz[sidx] = p0z + fma(A[8], lz, fma(A[7], ly, A[6] * lx));
-        sidx++;
-      }
-      q0 = fma(R[2], P.colli_length[i], q0);
-      q1 = fma(R[5], P.colli_length[i], q1);
-      q2 = fma(R[8], P.colli_length[i], q2);
-      if (i == 7) break;
-      joint_rotate(R, i, cq[i], sq[i]);
-    }
-    // sphere pairs (moma_traj_opt.cpp:1566-1611): screening only -- a positive clearance violation sends the pass to manipulator_block
-    double wall = -1.0;
-#pragma unroll
-    for (int a = 0; a < TOPAY_NSPH - 2; a++) {
-#pragma unroll
-      for (int b = a + 2; b < TOPAY_NSPH; b++) {
-        const double dx = Px[a] - Px[b], dy = Py[a] - Py[b], dz = Pz[a] - Pz[b];
-        wall = fmax(wall, P.pair_rr2[a * TOPAY_NSPH + b] - fma(dz, dz, fma(dy, dy, dx * dx)));
-      }
-    }
-    collides = wall > 0;
-#pragma unroll
-    for (int j = 0; j < SPG; j++) {
-      mx[j] = group_select<G>(g, Px, j);
-      my[j] = group_select<G>(g, Py, j);
-      mz[j] = group_select<G>(g, Pz, j);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 7; i++) mg_lds[i * 64] = cq[i];   // (as in manipulator_block: the cosines wait in the lane's LDS column)
-  double cost = 0.0, gdTk = 0.0;
-  const double wMC = P.s2_mani_colli_weight, wSC = P.s2_self_colli_weight;
-  // chassis top and environment collision of this group's spheres k = SPG g + j
-  double bFx = 0.0, bFy = 0.0, bMz = 0.0;
-  double lx_[SPG], ly_[SPG], lz_[SPG];
-  constexpr int LA = 1;
-  Esdf3dReq rq[LA + 1];
-  esdf3d_issue(M, mx[0], my[0], mz[0], rq[0]);
-#pragma unroll
-  for (int j = 0; j < SPG; j++) {
-    if (j + LA < SPG) esdf3d_issue(M, mx[j + LA], my[j + LA], mz[j + LA], rq[(j + LA) % (LA + 1)]);
-    const int k = SPG * g + j;
-    const double viol_k = P.sph_viol[k], top_k = P.sph_top[k];   // (lane-dependent index: vector loads from the constant block)
-    double Gx = 0.0, Gy = 0.0, Gz = 0.0;
-    if (k >= 3) {
-      const double height = top_k - mz[j];
-      if (height > 0) {
-        double pe, pd;
-        smoothL1(height, mu, pe, pd);
-        Gz += -w * wSC * pd;
-        gdTk += omg * wSC * (pe * TOPAY_INV_K);
-        cost += w * wSC * pe;
-      }
-    }
-    double d, gx, gy, gz;
-    esdf3d_finish(M, rq[j % (LA + 1)], d, gx, gy, gz);
-    const double viola = viol_k - d * 10.0;
-    if (viola > 0) {
-      double pe, pd;
-      smoothL1(viola, mu, pe, pd);
-      const double sc = -w * wMC * pd;
-      Gx += sc * gx * 10.0; Gy += sc * gy * 10.0; Gz += sc * gz * 10.0;
-      gdTk += omg * wMC * (pe * TOPAY_INV_K);
-      cost += w * wMC * pe;
-    }
-    bFx += Gx;
-    bFy += Gy;
-    bMz = fma(mx[j] - pos[0], Gy, fma(-(my[j] - pos[1]), Gx, bMz));
-    lx_[j] = fma(A[6], Gz, fma(A[3], Gy, A[0] * Gx));
-    ly_[j] = fma(A[7], Gz, fma(A[4], Gy, A[1] * Gx));
-    lz_[j] = fma(A[8], Gz, fma(A[5], Gy, A[2] * Gx));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // the chain walks of manipulator_block with the forces of the other groups' spheres at zero
-  double tau[7];
-  {
-    double Lx[TOPAY_NSPH], Ly[TOPAY_NSPH], Lz[TOPAY_NSPH];
-#pragma unroll
-    for (int k = 0; k < TOPAY_NSPH; k++) {
-      const bool mine = g == k / SPG;
-      Lx[k] = mine ? lx_[k % SPG] : 0.0;
-      Ly[k] = mine ? ly_[k % SPG] : 0.0;
-      Lz[k] = mine ? lz_[k % SPG] : 0.0;
-    }
-    double Fx = 0, Fy = 0, Fz = 0, Mx = 0, My = 0, Mz = 0;
-    {
-      double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-      double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-      int sidx = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int cnt = (i % 2 == 0) ? 2 : 1;
-#pragma unroll
-        for (int c = 0; c < cnt; c++) {
-          const double lx = fma(R[2], P.sph_off[sidx], q0), ly = fma(R[5], P.sph_off[sidx], q1), lz = fma(R[8], P.sph_off[sidx], q2);
-          Fx += Lx[sidx]; Fy += Ly[sidx]; Fz += Lz[sidx];
-          Mx = fma(ly, Lz[sidx], fma(-lz, Ly[sidx], Mx));
-          My = fma(lz, Lx[sidx], fma(-lx, Lz[sidx], My));
-          Mz = fma(lx, Ly[sidx], fma(-ly, Lx[sidx], Mz));
-          sidx++;
-        }
-        q0 = fma(R[2], P.colli_length[i], q0);
-        q1 = fma(R[5], P.colli_length[i], q1);
-        q2 = fma(R[8], P.colli_length[i], q2);
-        if (i == 7) break;
-        joint_rotate(R, i, mg_lds[i * 64], sq[i]);
-      }
-    }
-    {
-      double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
-      double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-      int sidx = 0;
-#pragma unroll
-      for (int i = 0; i < 7; i++) {
-        const int cnt = (i % 2 == 0) ? 2 : 1;
-#pragma unroll
-        for (int c = 0; c < cnt; c++) {
-          const double lx = fma(R[2], P.sph_off[sidx], o0), ly = fma(R[5], P.sph_off[sidx], o1), lz = fma(R[8], P.sph_off[sidx], o2);
-          Fx -= Lx[sidx]; Fy -= Ly[sidx]; Fz -= Lz[sidx];
-          Mx = fma(-ly, Lz[sidx], fma(lz, Ly[sidx], Mx));
-          My = fma(-lz, Lx[sidx], fma(lx, Lz[sidx], My));
-          Mz = fma(-lx, Ly[sidx], fma(ly, Lx[sidx], Mz));
-          sidx++;
-        }
-        o0 = fma(R[2], P.colli_length[i], o0);
-        o1 = fma(R[5], P.colli_length[i], o1);
-        o2 = fma(R[8], P.colli_length[i], o2);
-        const int ac = (i % 2 == 0) ? 2 : 1;
-        const double ax = R[0 * 3 + ac], ay = R[1 * 3 + ac], az = R[2 * 3 + ac];
-        const double tx = Mx - fma(o1, Fz, -(o2 * Fy));
-        const double ty = My - fma(o2, Fx, -(o0 * Fz));
-        const double tz = Mz - fma(o0, Fy, -(o1 * Fx));
-        tau[i] = fma(az, tz, fma(ay, ty, ax * tx));
-        joint_rotate(R, i, mg_lds[i * 64], sq[i]);
-      }
-    }
-  }
-  // across the groups, in a fixed order: every lane of a sample ends with the same totals
-  bFx = group_sum<G>(bFx); bFy = group_sum<G>(bFy); bMz = group_sum<G>(bMz);
-  cost = group_sum<G>(cost); gdTk = group_sum<G>(gdTk);
-#pragma unroll
-  for (int i = 0; i < 7; i++) tau[i] = group_sum<G>(tau[i]);
-  // joint position limits (per sample) — moma_traj_opt.cpp:1616-1666
-  const double wJP = P.s2_mani_pos_weight;
-#pragma unroll
-  for (int ji = 0; ji < 7; ji++) {
-    double v = pos[ji + 3] - P.joint_pos_limit_max[ji];
-    if (v > 0) {
-      double pe, pd;
-      smoothL1(v, mu, pe, pd);
-      tau[ji] += w * wJP * pd;
-      gdTk += omg * wJP * (pe * TOPAY_INV_K);
-      cost += w * wJP * pe;
-    }
-    v = -P.joint_pos_limit_max[ji] - pos[ji + 3];
-    if (v > 0) {
-      double pe, pd;
-      smoothL1(v, mu, pe, pd);
-      tau[ji] -= w * wJP * pd;
-      gdTk += omg * wJP * (pe * TOPAY_INV_K);
-      cost += w * wJP * pe;
-    }
-    mg_lds[ji * 64] = tau[ji];
-  }
-  ManiOutSplit out;
-  out.o.gx = bFx;
-  out.o.gy = bFy;
-  out.o.gth = bMz;
-  out.o.cost = cost;
-  out.o.gdT = gdTk;
-  out.fallback = collides ? 1 : 0;
-  return out;
-}
-
 // kinodynamic penalties shared by both stages — moma_traj_opt.cpp:1059-1115 / 1334-1462.
 // th1,th2,th3 = theta', theta'', theta'''; s1..s3 likewise.  Adds to cost, gdT and the gradBeta entries
 // (gth1 = d/d theta', gth2 = d/d theta'', gs1, gs2).
@@ -1404,15 +1140,6 @@ __device__ __forceinline__ ManiOut sample_mani(lds_cdp cL, int rows, int i, int 
   // `if`, this image's compiler puts those copies ahead of the EXEC restore of the join (docs/EXPERIMENTS.md, "The hardware-only failures";
   // tools/isa_lint.py found it again in round 4 when the callee's smaller register need changed the caller's allocation).
   if (topay_opaque_true()) mo_ = manipulator_block<OCC>(mp, cL, rows, i, j, half, step, posx, posy, act ? e : -1, mstash, mg_lds);
-  return mo_;
-}
-
-// The same for a short pass (at most 64 / G active samples): the lane's arguments are those of sample `lane mod (64 / G)`.
-template <int OCC, int G>
-__device__ __forceinline__ ManiOutSplit sample_mani_split(lds_cdp cL, int rows, int i, int j, double step, double half, double posx, double posy,
-                                                          const TOPAY_GLB DevMap* mp, int lane, lds_dp mg_lds) {
-  ManiOutSplit mo_;
-  if (topay_opaque_true()) mo_ = manipulator_block_split<OCC, G>(mp, cL, rows, i, j, half, step, posx, posy, lane, mg_lds);
   return mo_;
 }
 

@@ -431,34 +431,10 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
         ManiOut mo;
         mo.gx = mo.gy = mo.gth = mo.cost = mo.gdT = 0.0;
         if (STAGE == 2) {
-          // A short pass -- the last one of a candidate, 13 N mod 64 samples -- divides the spheres of its samples over 2 or 4
-          // lane groups (manipulator_block_split: about half the instructions of a call); a sample whose arm collides with
-          // itself sends the pass through the ordinary call instead.  (Wave-uniform decisions.)
-          const int n_act = NE - pass * 64;
-          bool whole = true;
-#ifndef TOPAY_NO_SPLIT_PASS
-          if (n_act <= 32) {
-            ManiOutSplit ms;
-            if (n_act <= 16) {
-              geometry(lane & 15);
-              ms = sample_mani_split<OCC, 4>(cL, rows, i, j, step, half, posx, posy, mp, lane, pbuf + lane);
-            } else {
-              geometry(lane & 31);
-              ms = sample_mani_split<OCC, 2>(cL, rows, i, j, step, half, posx, posy, mp, lane, pbuf + lane);
-            }
-            lane = fresh_lane_id(lane);
-            tid = wave * 64 + lane;
-            geometry(lane);
-            whole = __any(act && ms.fallback != 0) != 0;
-            mo = ms.o;
-          }
-#endif
-          if (whole) {
-            mo = sample_mani<OCC>(cL, rows, i, j, e, act, step, half, posx, posy, mp, c_mstash, pbuf + lane);
-            lane = fresh_lane_id(lane);
-            tid = wave * 64 + lane;
-            geometry(lane);
-          }
+          mo = sample_mani<OCC>(cL, rows, i, j, e, act, step, half, posx, posy, mp, c_mstash, pbuf + lane);
+          lane = fresh_lane_id(lane);
+          tid = wave * 64 + lane;
+          geometry(lane);
         }
         double gB[12], gdTs, gpx, gpy, cst;
         bool jva;
