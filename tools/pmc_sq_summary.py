@@ -14,7 +14,7 @@ for db in sorted(glob.glob(os.path.join(src, "p*", "pmc_results.db"))):
     kn = "kernel_name" if "kernel_name" in cols else "name"
     for name, cn, v in c.execute(f"select {kn}, counter_name, sum(value) from {view} group by {kn}, counter_name"):
         k = name.split("(")[0]
-        if "solve" in k or "eval" in k:
+        if "solve" in k or "eval" in k or "k_long" in k or "k_lat" in k:
             agg[k][cn] += v
 tot = collections.defaultdict(float)
 for k, d in agg.items():

@@ -29,7 +29,7 @@ def main(src, dst, tag, suffix=""):
     for r in rows:
         out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.0f} | {r[4]:.2f} |")
     cols, rows = q(kt, "select name, queue_id, start, end, duration, grid_x, lds_size, scratch_size, vgpr_count, "
-                       "accum_vgpr_count, sgpr_count from kernels where name like 'k_solve%' order by start")
+                       "accum_vgpr_count, sgpr_count from kernels where (name like 'k_solve%' or name like 'k_long%') order by start")
     t0 = rows[0][2]
     out.append("")
     out.append("## Solve-kernel dispatches (persistent: one per N-class, concurrent on one stream each; grid = the class's share of the SIMD slots)")
@@ -63,7 +63,7 @@ def main(src, dst, tag, suffix=""):
     # the default, pipelined command
     kt2 = os.path.join(src, "kt2", "kt_results.db")
     if os.path.exists(kt2):
-        cols, rows2 = q(kt2, "select name, queue_id, start, end, duration, grid_x from kernels where name like 'k_solve%' order by start")
+        cols, rows2 = q(kt2, "select name, queue_id, start, end, duration, grid_x from kernels where (name like 'k_solve%' or name like 'k_long%') order by start")
         t0 = rows2[0][2]
         out.append("")
         out.append("## Default command (three batches in flight): rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-config1 --no-serial")
@@ -112,7 +112,7 @@ def main(src, dst, tag, suffix=""):
         s = 0.0
         for r in rows:
             out.append(f"| `{r[0].split('(')[0]}` | {r[1]} | {r[2]:.0f} | {r[2] * 1024 / 3 / 1e9:.1f} |")
-            if r[0].startswith("k_solve"):
+            if r[0].startswith(("k_solve", "k_long")):
                 s += r[2] * 1024 / 3
         tot[ctr] = s
     cal = {}

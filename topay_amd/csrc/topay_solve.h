@@ -58,11 +58,20 @@ __device__ __forceinline__ bool vec_in(int tid, int t, int n) { return 2 * (NT *
 // the row's n-th element, so pairs beyond the row come back as zeros from the hardware's range check -- no index clamp
 // and no select per loaded value (the two-loop recursion is bound by instruction issue: 8 of its 48 vector instructions
 // per history pair were such selects).  The descriptor lives in scalar registers (uniform base).
+// STREAM: the load may carry a cache-policy hint (TOPAY_HIST_AUX, bits of a gfx940+ buffer instruction: 1 = sc0, 2 = nt,
+// 16 = sc1).  The (s, y) history of the two-loop recursion is read once per iteration -- 1.2 TB per step that no cache holds --
+// and pushes reused lines (scratch, parked rows, LU factors) out of L2.  Measured with nt = 1 (round 5, docs/EXPERIMENTS.md):
+// HBM-side writes - 20 %, reads + 6 %, strictly serial step + 4 % (the second loop re-reads the oldest pairs of the first
+// right away): off.
+#ifndef TOPAY_HIST_AUX
+#define TOPAY_HIST_AUX 0
+#endif
+template <bool STREAM = false>
 __device__ __forceinline__ dpair row_pair_or_zero(glb_cdp row, int n, int i) {
 #ifndef TOPAY_CPU_EMU
   typedef unsigned int u32x4 __attribute__((vector_size(16)));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, n * 8, 0x00020000);
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 0);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, STREAM ? TOPAY_HIST_AUX : 0);
   return __builtin_bit_cast(dpair, v);
 #else
   dpair q;
@@ -486,7 +495,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
 #pragma unroll
               for (int p = 0; p < EPL / 2; p++) {
                 const int i = NT * p + tid;
-                const dpair sv = row_pair_or_zero(sj, n, i), yv = row_pair_or_zero(yj, n, i);   // zeros beyond the row
+                const dpair sv = row_pair_or_zero<true>(sj, n, i), yv = row_pair_or_zero<true>(yj, n, i);   // zeros beyond the row; streaming
                 sb[slot][2 * p] = sv[0];
                 sb[slot][2 * p + 1] = sv[1];
                 yb[slot][2 * p] = yv[0];
