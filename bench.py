@@ -307,7 +307,9 @@ def main():
     o_full = opts[(args.steps - 1) % depth]
     stats = o_full.stats().copy()
     gate = o_full.check_feasible().copy()          # printConstraintsSituations over the batch (also part of every timed step)
-    waves_of = np.array([o_full.class_of(max(3, n_))[0] for n_ in range(0, 129)], dtype=np.float64)
+    # waves a candidate's WORKGROUP holds: one for the classes up to 32 pieces, four for the long classes (class index >= 4; their
+    # solver runs on the first wave -- topay_class_of reports the solver's division -- but all four hold their SIMD slots)
+    waves_of = np.array([4.0 if o_full.class_of(max(3, n_))[2] >= 4 else 1.0 for n_ in range(0, 129)], dtype=np.float64)
     # slot utilisation: device time of the candidates of one step summed (each is measured on the device's constant
     # clock from its first to its last instruction, times the SIMD slots its workgroup holds) over the SIMD slots there are
     slot_seconds = float((o_full.elapsed_us() * waves_of[np.clip(o_full.n_pieces(), 0, 128)]).sum() * 1e-6)

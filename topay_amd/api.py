@@ -688,7 +688,9 @@ class MomaTrajOptBatch:
         _chk(self.L, self.L.topay_load_solution(self.h, i, _dp(x), _dp(lam), _dp(rho)))
 
     def class_of(self, n_pieces):
-        """(waves per trajectory, elements per thread, class index) of the kernel that solves a candidate of n_pieces pieces."""
+        """(waves the solver's vectors are divided over, vector elements per thread of the solver, launch class index) of a candidate of
+        n_pieces pieces: what the bits of its solve depend on (since round 5 one wave for every class; the classes from index 4 up
+        -- more than 32 pieces -- evaluate on four waves)."""
         w, e, k = C.c_int(0), C.c_int(0), C.c_int(0)
         _chk(self.L, self.L.topay_class_of(int(n_pieces), C.byref(w), C.byref(e), C.byref(k)))
         return w.value, e.value, k.value

@@ -94,8 +94,15 @@ namespace topay {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
+#ifndef TOPAY_CPU_EMU
+  // (mov_dpp: no "old" operand -- with update_dpp(lo, lo, ...) the compiler copies the source into the destination first,
+  // two more 32-bit moves per level of every reduction: 8 of the 39 vector instructions per history pair of the two-loop recursion)
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+#else
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+#endif
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -120,8 +127,15 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]   : lane ^ 2
   v += dpp_f64<0x141>(v);  // row_half_mirror       : quad q <-> quad q^1
   v += dpp_f64<0x140>(v);  // row_mirror            : half h <-> half h^1
+#ifndef TOPAY_CPU_EMU
+  // Only lane 63 is read below: the rows a broadcast does not reach may hold anything, so the moves need no zeroed
+  // destination (two more 32-bit moves per level with the row masks of the emulator's form; lane 63's operands are the same).
+  v += dpp_f64<0x142>(v);             // row_bcast15: row k += lane 15 of row k - 1               -> lane 63: r3 + r2, lane 31: r1 + r0
+  v += dpp_f64<0x143>(v);             // row_bcast31: rows 2, 3 += lane 31                        -> lane 63: (r3 + r2) + (r1 + r0)
+#else
   v += dpp_f64_rows<0x142, 0xA>(v);   // row_bcast15: rows 1 and 3 += lane 15 of the row before  -> r1 + r0, r3 + r2
   v += dpp_f64_rows<0x143, 0xC>(v);   // row_bcast31: rows 2 and 3 += lane 31                    -> (r3 + r2) + (r1 + r0)
+#endif
   return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_max(double v) {
