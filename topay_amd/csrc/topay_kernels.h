@@ -378,7 +378,9 @@ TOPAY_SOLVE_KERNEL(k_solve3w2, 3, 2, 2)
 #endif  // TOPAY_NO_KERNEL_TABLE
 
 // feasibility gate (printConstraintsSituations / checkFeasible) of every candidate's returned trajectory
-__global__ void __launch_bounds__(64) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
+// (two waves per SIMD like the solve kernels: 256 registers, no AGPRs -- with 512 the allocator parked values in AGPRs, whose
+// copies are what this image's compiler can misplace at a control-flow join, tools/isa_lint.py)
+__global__ void __launch_bounds__(64, 2) k_feasible(DevBatch Bt, const DevMap* maps, double* cseq, double* tk, long long cap_panels,
                                                  long long cap_samples, double* report, int* flags) {
   const int b = blockIdx.x;
   const int N = Bt.N[b];
