@@ -96,6 +96,10 @@ def track_agreement(name, values, band=0.05):
     except OSError:
         gold = {}
     assert name in gold, f"no committed agreement figures for {name}: measured {allm[name]}"
+    # same_winner is a fraction of ~150 scenarios (standard deviation 0.04 between two arithmetic variants of the SAME algorithm:
+    # round 5 measured 0.548 and 0.487 for two builds whose evaluations differ in the last bit): its band is twice the others'
+    wide = {"same_winner": 2.0, "winner_duration_within_5pct": 1.5}
     for k, g in gold[name].items():
         assert k in values, (name, k)
-        assert abs(float(values[k]) - g) <= band, f"{name}.{k}: measured {float(values[k]):.4f}, committed {g:.4f} (band {band})"
+        b = band * wide.get(k, 1.0)
+        assert abs(float(values[k]) - g) <= b, f"{name}.{k}: measured {float(values[k]):.4f}, committed {g:.4f} (band {b})"
