@@ -508,6 +508,8 @@ def main():
             "config1_latency": cfg1,
             "planner_semantics": planner,
             "workspace_bytes_per_context": int(opt.workspace_bytes()), "contexts": depth,
+            # the batches in flight against the device's memory (maps are shared between the contexts and not in the figure: 5.4 MB each)
+            "workspace_fraction_of_hbm": float(opt.workspace_bytes()) * depth / float(torch.cuda.get_device_properties(dev_index).total_memory),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

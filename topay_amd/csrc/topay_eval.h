@@ -378,10 +378,19 @@ __device__ __forceinline__ void esdf3d_query(const DevMap& M, double px, double 
 
 // The same lookup split in two so that the gathers of the next sphere can be in flight while the penalties of the
 // current one (divergent branches the scheduler will not move loads across) are evaluated.
+//
+// Four 16-byte gathers instead of eight 8-byte ones (round 5).  The two z-neighbours of a corner pair are adjacent doubles of
+// the field (x-major, z fastest), so one load fetches both: the pair starts at zb = min(z0, nz - 2) and the clamped indices z0,
+// z1 (equal at either face of the map) pick their element of it -- the same eight values into the same arithmetic, half the
+// vector-memory instructions.  A gather costs the compute unit's L1 one tag lookup per lane whatever its width, and eight waves
+// of a compute unit share that L1: 96 -> 48 such instructions per call of the manipulator block.  (The loads are 8-byte
+// aligned; a pair that straddles a cache line costs two lookups, one case in eight or sixteen.  nz >= 2 is checked when a map
+// is set: with a single layer the pair would reach past the field.)
+typedef double esdf_pair __attribute__((vector_size(16), aligned(8)));
 struct Esdf3dReq {
-  double v000, v001, v010, v011, v100, v101, v110, v111;
+  esdf_pair p00, p01, p10, p11;   // (z pair) of the rows (x0, y0), (x0, y1), (x1, y0), (x1, y1)
   double dx, dy, dz;
-  bool in;
+  bool in, z0hi, z1hi;            // z0 / z1 is the pair's second element
 };
 __device__ __forceinline__ void esdf3d_issue(const DevMap& M, double px, double py, double pz, Esdf3dReq& q) {
   q.in = !(px < M.min_b[0] + 1e-4 || py < M.min_b[1] + 1e-4 || pz < M.min_b[2] + 1e-4 ||
@@ -399,35 +408,51 @@ __device__ __forceinline__ void esdf3d_issue(const DevMap& M, double px, double 
   clamp_pair(iy, ny - 1, y0, y1);
   clamp_pair(iz, nz - 1, z0, z1);
   glb_cdp e = M.esdf3d;
-  // One linear index with a multiply (integer multiplies run at a quarter of the vector rate), the other seven corners by
-  // adding the strides of the axes along which the clamped neighbour differs (x1 - x0, y1 - y0, z1 - z0 are 0 or 1).  A
-  // field has fewer than 2^32 cells (checked when the map is set), so the indices are 32-bit.
-  const unsigned i000 = ((unsigned)x0 * (unsigned)ny + (unsigned)y0) * (unsigned)nz + (unsigned)z0;
-  const unsigned sx = x1 != x0 ? (unsigned)(ny * nz) : 0u, sy = y1 != y0 ? (unsigned)nz : 0u, sz = z1 != z0 ? 1u : 0u;
-  const unsigned i001 = i000 + sz, i010 = i000 + sy, i100 = i000 + sx;
-  const unsigned i011 = i010 + sz, i101 = i100 + sz, i110 = i100 + sy;
-  const unsigned i111 = i110 + sz;
-  q.v000 = e[(size_t)i000]; q.v001 = e[(size_t)i001]; q.v010 = e[(size_t)i010]; q.v011 = e[(size_t)i011];
-  q.v100 = e[(size_t)i100]; q.v101 = e[(size_t)i101]; q.v110 = e[(size_t)i110]; q.v111 = e[(size_t)i111];
+  // One linear index with a multiply (integer multiplies run at a quarter of the vector rate), the other rows by adding the
+  // strides of the axes along which the clamped neighbour differs (x1 - x0, y1 - y0 are 0 or 1).  A field has fewer than
+  // 2^32 cells (checked when the map is set), so the indices are 32-bit.
+  const int zb = z0 < nz - 2 ? z0 : nz - 2;
+  q.z0hi = z0 != zb;
+  q.z1hi = z1 != zb;
+  const unsigned i00 = ((unsigned)x0 * (unsigned)ny + (unsigned)y0) * (unsigned)nz + (unsigned)zb;
+  const unsigned sx = x1 != x0 ? (unsigned)(ny * nz) : 0u, sy = y1 != y0 ? (unsigned)nz : 0u;
+  const unsigned i01 = i00 + sy, i10 = i00 + sx;
+  const unsigned i11 = i10 + sy;
+#ifndef TOPAY_CPU_EMU
+  typedef const TOPAY_GLB esdf_pair* pair_ptr;
+  q.p00 = *(pair_ptr)(e + (size_t)i00);
+  q.p01 = *(pair_ptr)(e + (size_t)i01);
+  q.p10 = *(pair_ptr)(e + (size_t)i10);
+  q.p11 = *(pair_ptr)(e + (size_t)i11);
+#else
+  q.p00[0] = e[(size_t)i00]; q.p00[1] = e[(size_t)i00 + 1];
+  q.p01[0] = e[(size_t)i01]; q.p01[1] = e[(size_t)i01 + 1];
+  q.p10[0] = e[(size_t)i10]; q.p10[1] = e[(size_t)i10 + 1];
+  q.p11[0] = e[(size_t)i11]; q.p11[1] = e[(size_t)i11 + 1];
+#endif
 }
 __device__ __forceinline__ void esdf3d_finish(const DevMap& M, const Esdf3dReq& q, double& dist, double& gx, double& gy,
                                               double& gz) {
   const double ri = M.res_inv;
   const double dx = q.dx, dy = q.dy, dz = q.dz;
   const double ex = 1 - dx, ey = 1 - dy, ez = 1.0 - dz;
-  double v00 = fma(q.v100, dx, q.v000 * ex);
-  double v01 = fma(q.v101, dx, q.v001 * ex);
-  double v10 = fma(q.v110, dx, q.v010 * ex);
-  double v11 = fma(q.v111, dx, q.v011 * ex);
+  const double v000 = q.z0hi ? q.p00[1] : q.p00[0], v001 = q.z1hi ? q.p00[1] : q.p00[0];
+  const double v010 = q.z0hi ? q.p01[1] : q.p01[0], v011 = q.z1hi ? q.p01[1] : q.p01[0];
+  const double v100 = q.z0hi ? q.p10[1] : q.p10[0], v101 = q.z1hi ? q.p10[1] : q.p10[0];
+  const double v110 = q.z0hi ? q.p11[1] : q.p11[0], v111 = q.z1hi ? q.p11[1] : q.p11[0];
+  double v00 = fma(v100, dx, v000 * ex);
+  double v01 = fma(v101, dx, v001 * ex);
+  double v10 = fma(v110, dx, v010 * ex);
+  double v11 = fma(v111, dx, v011 * ex);
   double v0 = fma(v10, dy, v00 * ey);
   double v1 = fma(v11, dy, v01 * ey);
   dist = fma(v1, dz, v0 * ez);
   gz = (v1 - v0) * ri;
   gy = fma(v11 - v01, dz, (v10 - v00) * ez) * ri;
-  double g0 = ez * ey * (q.v100 - q.v000);
-  g0 = fma(ez * dy, q.v110 - q.v010, g0);
-  g0 = fma(dz * ey, q.v101 - q.v001, g0);
-  g0 = fma(dz * dy, q.v111 - q.v011, g0);
+  double g0 = ez * ey * (v100 - v000);
+  g0 = fma(ez * dy, v110 - v010, g0);
+  g0 = fma(dz * ey, v101 - v001, g0);
+  g0 = fma(dz * dy, v111 - v011, g0);
   gx = g0 * ri;
   dist = q.in ? dist : 0.0; gx = q.in ? gx : 0.0; gy = q.in ? gy : 0.0; gz = q.in ? gz : 0.0;
 }
@@ -936,13 +961,13 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
     double d, gx, gy, gz;
 #ifdef TOPAY_STAMPS
     {
-      // exposed latency of this sphere's eight gathers: cycles until they have returned (the 8 min(LA, spheres left)
+      // exposed latency of this sphere's four pair gathers: cycles until they have returned (the 4 min(LA, spheres left)
       // issued after them may stay in flight), measured where the first of them is needed
       const long long w0_ = (long long)__builtin_amdgcn_s_memtime();
-      constexpr int FULL = 8 * LA;   // s_waitcnt vmcnt(n): expcnt / lgkmcnt fields left at their maxima
+      constexpr int FULL = 4 * LA;   // (four pair gathers per sphere) s_waitcnt vmcnt(n): expcnt / lgkmcnt fields left at their maxima
       const int left = TOPAY_NSPH - 1 - k;
       if (left >= LA) __builtin_amdgcn_s_waitcnt(0x0f70 | (FULL & 15) | ((FULL >> 4) << 14));
-      else if (left == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 8);
+      else if (left == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
       else __builtin_amdgcn_s_waitcnt(0x0f70);
       const long long w1_ = (long long)__builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && threadIdx.x == 0) { g_mani_stamps[6] += w1_ - w0_; g_mani_stamps[7] += 1; }

@@ -615,6 +615,7 @@ topay_status topay_set_map(topay_ctx* c, int map_id, const topay_map_desc_t* des
   const size_t n2 = (size_t)desc->dims[0] * desc->dims[1], n3 = n2 * desc->dims[2];
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
   if (n3 >= (1ull << 32)) { set_err("map of 2^32 cells or more (the lookups index a field with 32 bits)"); return TOPAY_ERR_UNSUPPORTED; }
+  if (desc->dims[2] < 2) { set_err("3-D field with a single layer (the lookups fetch z-neighbours in pairs)"); return TOPAY_ERR_UNSUPPORTED; }
   invalidate_sharers(c, map_id, 1);
   drop_shared_slots(c, map_id, 1);
   topay_status s;
@@ -735,6 +736,7 @@ topay_status topay_build_esdf_fields(topay_ctx* c, int n_maps, int first_map_id,
   const size_t n2 = (size_t)nx * ny, n3 = n2 * nz, M = (size_t)n_maps;
   if (n2 == 0 || n3 == 0) return TOPAY_ERR_INVALID_ARG;
   if (n3 >= (1ull << 32)) { set_err("map of 2^32 cells or more (the lookups index a field with 32 bits)"); return TOPAY_ERR_UNSUPPORTED; }
+  if (desc->dims[2] < 2) { set_err("3-D field with a single layer (the lookups fetch z-neighbours in pairs)"); return TOPAY_ERR_UNSUPPORTED; }
   invalidate_sharers(c, first_map_id, n_maps);
   drop_shared_slots(c, first_map_id, n_maps);
   topay_status s;
