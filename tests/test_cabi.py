@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 import __graft_entry__ as entry
@@ -310,3 +311,16 @@ def test_a_slot_shared_from_a_sharer_follows_the_context_that_holds_the_fields(c
     with pytest.raises(api.TopayError):
         c.set_init_traj(cs["lens"][:2], cs["paths"][:cs["offs"][2]])
     c.close()
+
+
+def test_a_field_with_a_single_z_layer_is_refused(cuboids_small):
+    """The ESDF lookups of the evaluation fetch the two z-neighbours of a corner pair with one 16-byte load (round 5): with a
+    single layer the pair would reach past the field, so such a map is refused when it is set (the reference's maps have 16)."""
+    from conftest import EMU_LIB
+    w = cuboids_small["world"]
+    o = api.MomaTrajOptBatch(lib_path=EMU_LIB)
+    dims = np.array([w.dims[0], w.dims[1], 1], dtype=np.int32)
+    e3 = np.ascontiguousarray(w.esdf3d.reshape(w.dims[0], w.dims[1], w.dims[2])[:, :, :1])
+    with pytest.raises(api.TopayError):
+        o.set_map(w.origin, w.res, dims, w.min_b, w.max_b, w.esdf2d, e3)
+    o.close()
