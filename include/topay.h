@@ -203,8 +203,8 @@ topay_status topay_get_map_fields(topay_ctx* ctx, int map_id, double* esdf2d_inf
  *                    (row 0 = v, row 1 = omega, rows 3-9 = joints; col 0 = start, col 1 = end); NULL = zeros
  *   map_ids          map slot per candidate, NULL = all slot 0
  * Uploads the raw paths (they stay resident), runs the init kernel, sizes the workspace.
- * The reference puts no bound on the number of pieces (moma_traj_opt.cpp:245, 300-321); this build solves up to 128
- * (a 192 s trajectory at the reference's 1.5 s sample_interval: what a four-wave workgroup holds in a compute unit's LDS).  A
+ * The reference puts no bound on the number of pieces (moma_traj_opt.cpp:245, 300-321); this build solves up to 170
+ * (a 255 s trajectory at the reference's 1.5 s sample_interval: what a four-wave workgroup holds in a compute unit's LDS).  A
  * candidate that needs more is reported as failed (success 0, cost NaN, n_pieces 0) without being launched and the
  * rest of the batch is solved normally; topay_get_batch's n_pieces lets the caller count such candidates. */
 topay_status topay_set_init_traj(topay_ctx* ctx, int batch, const int* path_len, const double* init_paths,
@@ -390,7 +390,7 @@ topay_status topay_get_x(topay_ctx* ctx, int i, int* n, double* x);
 topay_status topay_eval(topay_ctx* ctx, int stage, int i, const double* x, const double* alm_lambda,
                         const double* alm_rho, double* f, double* g, double* final_xy_error);
 
-/* Test hook: topay_eval by the kernel with `waves` wavefronts per trajectory (1: N <= 64, 2: N <= 64, 4: N <= 128)
+/* Test hook: topay_eval by the kernel with `waves` wavefronts per trajectory (1: N <= 64, 2: N <= 64, 4: N <= 170)
  * instead of the candidate's class default.  The evaluation is order-identical for any number of waves: f, g and the
  * end-point error must come out bit for bit equal. */
 topay_status topay_eval_waves(topay_ctx* ctx, int stage, int i, int waves, const double* x, const double* alm_lambda,

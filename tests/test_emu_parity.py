@@ -224,9 +224,9 @@ def test_three_rows_per_lane_class(cuboids_small):
 def test_long_classes_and_too_long_paths(cuboids_small):
     """N in 33..64 (the reference has no cap, moma_traj_opt.cpp:245, 300-321) runs in the classes of long candidates
     (several waves per trajectory by default, tests/test_multiwave.py): packed initial guess and per-evaluation parity at
-    N = 33, 48 and 64, three kinds of points.  Beyond 128 pieces the candidate is reported as failed without a solve."""
+    N = 33, 48 and 64, three kinds of points.  Beyond 170 pieces the candidate is reported as failed without a solve."""
     cs = cuboids_small
-    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 134.5)]
+    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 178.0)]
     opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
     set_map(opt, cs["world"])
     opt.set_init_traj(np.array([len(p) for p in paths], dtype=np.int32), np.concatenate(paths))
@@ -253,7 +253,7 @@ def test_long_classes_and_too_long_paths(cuboids_small):
                 assert abs(f - fe) <= 1e-12 * abs(f) and np.abs(g - ge).max() <= 1e-11 * np.abs(g).max(), (Nk, trial, stage)
     o_long = orc.Oracle(cs["map"])
     o_long.set_init_traj(paths[3])
-    assert o_long.N > 128
+    assert o_long.N > 170
     with pytest.raises(api.TopayError):
         opt.get_x(3)
     r = opt.getTraj(3)

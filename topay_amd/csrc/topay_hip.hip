@@ -118,7 +118,7 @@ static const int kBigFirst = 4;   // the classes of long candidates (N > 32) sta
 
 // Kernel of a launch class: rows per thread and waves per trajectory select the template; the LDS is sized by the
 // longest candidate actually in the class.  The classes of long candidates have a one-wave and a several-waves variant
-// (TOPAY_MW_C4 / TOPAY_MW_C5 = waves per trajectory for N <= 42 / N <= 64; N <= 128 always runs on four waves).
+// (TOPAY_MW_C4 / TOPAY_MW_C5 = waves per trajectory for N <= 42 / N <= 64; N <= 170 always evaluates on four waves).
 typedef void (*solve_kernel_t)(DevBatch, const DevMap*, int);
 typedef void (*eval_kernel_t)(DevBatch, const DevMap*, int, int, int);
 struct ClassDef {
@@ -142,14 +142,14 @@ static const ClassDef* class_table() {
         {10, 1, 1, k_solve1, k_eval1, 2, k_lat1}, {15, 2, 1, k_solve2, k_eval2, 2, k_lat2}, {21, 2, 1, k_solve2, k_eval2, 2, k_lat2},
         {32, 3, 1, k_solve3, k_eval3, 2, k_lat3},
         {42, 2, 4, k_long5, k_eval2w4, 2, nullptr, 1, 5, true}, {64, 2, 4, k_long5, k_eval2w4, 2, nullptr, 1, 5, true},
-        {TOPAY_MAX_N, 3, 4, k_long10, k_eval3w4, 2, nullptr, 1, 10, true}};
+        {TOPAY_MAX_N, 4, 4, k_long14, k_eval4w4, 2, nullptr, 1, 14, true}};
     // Four waves per trajectory for N = 33..64 since round 4.  Round 3 (one wave per SIMD), one / two / four waves for both
     // classes: 9.8-10.1k / 10.1k / 9.1k trajectories/s, strictly serial steps 1.15 / 1.00 / 1.03 s -- four waves halve a long
     // candidate's solve but held four SIMDs for it.  With two waves per SIMD a wave holds half a SIMD, the common classes
     // got faster and the long candidates set the length of a batch again (their launch was the longest of a serial step,
     // 1.06-1.21 s): two / four waves for N = 43..64 now give 11.5-11.6k / 11.8-11.9k and serial steps of 1.07 / 0.95 s, four
     // for N = 33..42 as well 0.94 s (tools/experiments/r4_mw.sh).
-    // Round 5: the SOLVER of the long classes runs on one wave (k_long5 / k_long10: 10 / 20 vector elements per lane) and only
+    // Round 5: the SOLVER of the long classes runs on one wave (k_long5 / k_long14: 10 / 28 vector elements per lane) and only
     // the evaluations use the four waves -- every reduction of the four-wave solver (two per history pair of the two-loop
     // recursion) was a workgroup reduction through LDS and a barrier (k_solve2w4: VALU active 18.7 % of its wave cycles).
 #ifdef TOPAY_EXPERIMENTS
@@ -164,7 +164,7 @@ static const ClassDef* class_table() {
       if (atoi(e) == 4) {
         if (w4 == 4) t[4] = {42, 2, 4, k_solve2w4, k_eval2w4, 2};
         if (w5 == 4) t[5] = {64, 2, 4, k_solve2w4, k_eval2w4, 2};
-        t[6] = {TOPAY_MAX_N, 3, 4, k_solve3w4, k_eval3w4, 2};
+        t[6] = {128, 3, 4, k_solve3w4, k_eval3w4, 2};   // (the four-wave solver holds 128 pieces: longer candidates are not launched in this A/B mode)
       }
     }
 #endif
@@ -1067,7 +1067,7 @@ topay_status topay_set_init_traj(topay_ctx* c, int batch, const int* path_len, c
   HIPCHK(memcpy_sync(c, c->poff.p, c->h_poff.data(), ((size_t)batch + 1) * 8, hipMemcpyHostToDevice));
   HIPCHK(memcpy_sync(c, c->noff.p, c->h_noff.data(), ((size_t)batch + 1) * 8, hipMemcpyHostToDevice));
   // every block sized by the candidates' own pieces / decision vectors (the history, 2 m n doubles per candidate, is
-  // by far the largest: 0.4 MB at the benchmark's mean of 11 pieces, 5 MB at 128)
+  // by far the largest: 0.4 MB at the benchmark's mean of 11 pieces, 7 MB at 170)
   ENS(x, NN * 8);
   ENS(work, 4 * NN * 8);
   ENS(hist_s, (size_t)m * NN * 8);
@@ -2134,9 +2134,9 @@ static bool class_for_waves(int N, int nw, ClassDef& out) {
   static const ClassDef w1[] = {{10, 1, 1, nullptr, k_eval1, 2}, {21, 2, 1, nullptr, k_eval2, 2}, {32, 3, 1, nullptr, k_eval3, 2},
                                 {42, 4, 1, nullptr, k_eval4, 2}, {64, 6, 1, nullptr, k_eval6, 2}};
   static const ClassDef w2[] = {{42, 2, 2, nullptr, k_eval2w2, 2}, {64, 3, 2, nullptr, k_eval3w2, 2}};
-  static const ClassDef w4[] = {{85, 2, 4, nullptr, k_eval2w4, 2}, {TOPAY_MAX_N, 3, 4, nullptr, k_eval3w4, 2}};
+  static const ClassDef w4[] = {{85, 2, 4, nullptr, k_eval2w4, 2}, {128, 3, 4, nullptr, k_eval3w4, 2}, {TOPAY_MAX_N, 4, 4, nullptr, k_eval4w4, 2}};
   const ClassDef* t = nw == 1 ? w1 : (nw == 2 ? w2 : (nw == 4 ? w4 : nullptr));
-  const int cnt = nw == 1 ? 5 : 2;
+  const int cnt = nw == 1 ? 5 : (nw == 4 ? 3 : 2);
   if (!t) return false;
   for (int k = 0; k < cnt; k++)
     if (N <= t[k].max_n) { out = t[k]; return true; }

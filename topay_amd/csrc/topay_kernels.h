@@ -347,10 +347,10 @@ __device__ __forceinline__ void solve_body(const DevBatch& Bt, const DevMap* map
 TOPAY_SOLVE_KERNEL(k_solve1, 1, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve2, 2, 1, 2)
 TOPAY_SOLVE_KERNEL(k_solve3, 3, 1, 2)
-// the long classes (N = 33..64 / 65..128): one-wave solver with 10 / 20 vector elements per lane on wave 0, evaluations on
-// four waves with 2 / 3 system rows per thread
+// the long classes (N = 33..64 / 65..170): one-wave solver with 10 / 28 vector elements per lane on wave 0, evaluations on
+// four waves with 2 / 4 system rows per thread
 TOPAY_LATENCY_KERNEL(k_long5, 5, 2, 4, 2)
-TOPAY_LATENCY_KERNEL(k_long10, 10, 3, 4, 2)
+TOPAY_LATENCY_KERNEL(k_long14, 14, 4, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat1, 1, 1, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat2, 2, 1, 4, 2)
 TOPAY_LATENCY_KERNEL(k_lat3, 3, 1, 4, 2)
@@ -360,6 +360,7 @@ TOPAY_EVAL_KERNEL(k_eval3, 3, 1, 2)
 TOPAY_EVAL_KERNEL(k_eval2w2, 2, 2, 2)
 TOPAY_EVAL_KERNEL(k_eval3w2, 3, 2, 2)
 TOPAY_EVAL_KERNEL(k_eval3w4, 3, 4, 2)
+TOPAY_EVAL_KERNEL(k_eval4w4, 4, 4, 2)
 // evaluation only (test hook topay_eval_waves: one wave for N = 33..64, four waves for N <= 85 -- the references of the
 // order-identity tests of the several-waves evaluation)
 TOPAY_EVAL_KERNEL(k_eval4, 4, 1, 2)

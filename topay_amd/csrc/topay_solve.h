@@ -471,7 +471,8 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             // every wait a full drain), and every load is issued unconditionally so that the number outstanding is
             // static: the alpha values live in LDS (256 doubles) and the prefetch keeps running past the end (it re-reads
             // valid, unused rows).
-            constexpr int PF = TOPAY_PF_ELEMS / EPL < TOPAY_PF_MAX ? TOPAY_PF_ELEMS / EPL : TOPAY_PF_MAX;  // pairs in flight
+            constexpr int PF0 = TOPAY_PF_ELEMS / EPL < TOPAY_PF_MAX ? TOPAY_PF_ELEMS / EPL : TOPAY_PF_MAX;
+            constexpr int PF = PF0 < 1 ? 1 : PF0;  // pairs in flight (at least one: 28 elements per lane in the longest class)
             SUBSTAMP_BEGIN(C);
             double dr[EPL];
             {

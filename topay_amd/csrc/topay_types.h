@@ -6,13 +6,13 @@
 #define TOPAY_SP 25         // samples per piece = 2K+1
 #define TOPAY_EP 13         // even ("full") samples per piece = K+1
 #define TOPAY_NSPH 12       // collision spheres (moma_param.h:94-109)
-// Pieces per trajectory this build solves: 128 (a 192 s trajectory at the reference's 1.5 s sample_interval): 768 system
-// rows = 3 per thread of a four-wave workgroup (124 KB of the 160 KB of LDS of a compute unit, topay_eval_mw.h).  Launch
-// classes: N <= 10 / 15 / 21 / 32 one wave per trajectory (1 / 2 / 2 / 3 system rows per lane), N <= 42 / 64 / 128 four
-// waves (2 / 2 / 3 rows per thread).  The reference itself has no cap (moma_traj_opt.cpp:245,
-// 300-321); longer candidates are reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them
-// as n_not_launched).
-#define TOPAY_MAX_N 128
+// Pieces per trajectory this build solves: 170 (a 255 s trajectory at the reference's 1.5 s sample_interval) -- what the LDS of a
+// compute unit holds: 1020 system rows = 4 per thread of a four-wave workgroup and 158 of the 160 KB (topay_eval_mw.h); the
+// one-wave solver of that class keeps 28 vector elements per lane (1792 >= 10 N - 8).  Launch classes: N <= 10 / 15 / 21 / 32
+// one wave per trajectory (1 / 2 / 2 / 3 system rows per lane), N <= 42 / 64 / 170 four waves in the evaluations (2 / 2 / 4 rows
+// per thread) with the solver on the first.  The reference itself has no cap (moma_traj_opt.cpp:245, 300-321); longer
+// candidates are reported failed without a solve (success 0, cost NaN, n_pieces 0; bench.py counts them as n_not_launched).
+#define TOPAY_MAX_N 170
 #define TOPAY_NBUCKET 7
 #define TOPAY_WAVE 64
 
