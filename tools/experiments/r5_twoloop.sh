@@ -1,0 +1,17 @@
+#!/bin/bash
+# two-loop recursion with 32-bit row offsets, step-indexed alpha ring and branch-free groups of PF steps (42 instead of 62
+# instructions per history pair): hash (must stay 0dbe2e2a1efb9921), solver tests, planning call (configs[1]) by phase, and the
+# bench, previous build (tools/libs/libtopay_prev10.so) against the tree, interleaved
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+O=gpurun_out/r5twoloop; mkdir -p $O
+echo "hash: $(timeout 600 python3 tools/gpu_hashrun.py 2>/dev/null | tail -1)   (before: 0dbe2e2a1efb9921)"
+TOPAY_LIB=tools/libs/libtopay_stamps.so timeout 600 python3 tools/gpu_stamps_cfg1.py 2>&1 | grep -v "^     (" | tail -40
+timeout -s KILL 1500 python3 -m pytest tests/test_multiwave.py tests/test_gpu_parity.py -m gpu -q -x > $O/tests.log 2>&1; tail -2 $O/tests.log
+A="--steps 12 --warmup 3 --no-cpu-baseline --no-planner"
+for r in 1 2 3; do for v in prev10 tree; do
+  if [ $v = tree ]; then unset TOPAY_LIB; else export TOPAY_LIB=$PWD/tools/libs/libtopay_$v.so; fi
+  timeout -s KILL 400 python3 bench.py $A > $O/$v$r.json 2> $O/$v$r.err; python3 tools/pj.py $v$r < $O/$v$r.json || tail -3 $O/$v$r.err
+  python3 -c "
+import json,sys; j=json.load(open('$O/$v$r.json')); c=j['config']['config1_latency']; print('   configs[1] %.1f ms default, %.1f ms helper waves' % (c['solve_ms'], c['solve_ms_latency_mode']))"
+done; done
+unset TOPAY_LIB

@@ -490,9 +490,16 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
             // sees that they were derived from vector compares)
             const int endu = __builtin_amdgcn_readfirstlane(end), boundu = __builtin_amdgcn_readfirstlane(bound);
             const int memu = __builtin_amdgcn_readfirstlane(mem), nstr = __builtin_amdgcn_readfirstlane(S.nstride);
+            // Row addresses as 32-bit byte offsets from the two history blocks (a candidate's history is < 4 GB): one scalar
+            // multiply per pair instead of a 64-bit product and shift, and the alpha ring is indexed by the STEP of the first
+            // loop (the second loop walks the same pairs backwards, so it reads alpha[bound - 1 - i]) -- a lone wave issues
+            // one instruction per four cycles whatever its kind, and 27 of the 60 per history pair were this bookkeeping.
+            const unsigned rbytes = (unsigned)nstr * 8u;
+            typedef const TOPAY_GLB char* glb_ccp;
             auto load_pair = [&](int slot, int jj) {
-              const glb_cdp sj = S.hist_s + (size_t)jj * nstr;
-              const glb_cdp yj = S.hist_y + (size_t)jj * nstr;
+              const unsigned ro = (unsigned)jj * rbytes;
+              const glb_cdp sj = (glb_cdp)((glb_ccp)S.hist_s + ro);
+              const glb_cdp yj = (glb_cdp)((glb_ccp)S.hist_y + ro);
 #pragma unroll
               for (int p = 0; p < EPL / 2; p++) {
                 const int i = NT * p + tid;
@@ -502,62 +509,66 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                 yb[slot][2 * p] = yv[0];
                 yb[slot][2 * p + 1] = yv[1];
               }
-              rb[slot] = S.hist_ys[jj];
+              rb[slot] = *(glb_cdp)((glb_ccp)S.hist_ys + (unsigned)jj * 8u);
             };
+            // Each loop runs whole groups of PF steps without a branch inside (the scalar bookkeeping of the next load then
+            // fills the wait states the DPP moves of a reduction need anyway), then the < PF steps left over, which find
+            // their pairs already in the ring.
             // ---- first loop: newest pair first.  Pair index of step i: (end - 1 - i) mod mem
+            auto step1 = [&](int u, int i) {
+              double part = 0.0;
+#pragma unroll
+              for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
+              const double al = wsum(part) * rb[u];
+              alpha[i] = al;
+#pragma unroll
+              for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
+            };
             int jl = endu;  // next pair to load (walks down, wrapping)
 #pragma unroll
             for (int u = 0; u < PF; u++) { jl = jl == 0 ? memu - 1 : jl - 1; load_pair(u, jl); }
-            int jlast = endu, jc = endu;  // jc: pair being processed
-            for (int i0 = 0; i0 < boundu; i0 += PF) {
+            int i0 = 0;
+            for (; i0 + PF <= boundu; i0 += PF) {
 #pragma unroll
               for (int u = 0; u < PF; u++) {
-                const int i = i0 + u;
-                if (i < boundu) {
-                  jc = jc == 0 ? memu - 1 : jc - 1;
-                  const int j = jc;
-                  double part = 0.0;
-#pragma unroll
-                  for (int t = 0; t < EPL; t++) part = fma(sb[u][t], dr[t], part);
-                  const double al = wsum(part) * rb[u];
-                  alpha[j] = al;
-#pragma unroll
-                  for (int t = 0; t < EPL; t++) dr[t] = fma(-al, yb[u][t], dr[t]);
-                  jlast = j;
-                }
+                step1(u, i0 + u);
                 jl = jl == 0 ? memu - 1 : jl - 1;
                 load_pair(u, jl);
               }
             }
+#pragma unroll
+            for (int u = 0; u < PF - 1; u++)
+              if (i0 + u < boundu) step1(u, i0 + u);
             const double scl = ys / yy;
 #pragma unroll
             for (int t = 0; t < EPL; t++) dr[t] *= scl;
             lds_sync();  // alpha entries written above are read below
-            // ---- second loop: oldest pair first.  Pair index of step i: (jlast + i) mod mem
-            jl = jlast;  // next pair to load (walks up, wrapping)
+            // ---- second loop: oldest pair first.  Pair index of step i: (end - bound + i) mod mem
+            auto step2 = [&](int u, int i) {
+              const double av = alpha[boundu - 1 - i];
+              double part = 0.0;
+#pragma unroll
+              for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
+              const double beta = wsum(part) * rb[u];
+              const double co = av - beta;
+#pragma unroll
+              for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
+            };
+            jl = endu - boundu;  // next pair to load (walks up, wrapping)
+            jl = jl < 0 ? jl + memu : jl;
 #pragma unroll
             for (int u = 0; u < PF; u++) { load_pair(u, jl); jl = jl + 1 == memu ? 0 : jl + 1; }
-            jc = jlast;
-            for (int i0 = 0; i0 < boundu; i0 += PF) {
+            for (i0 = 0; i0 + PF <= boundu; i0 += PF) {
 #pragma unroll
               for (int u = 0; u < PF; u++) {
-                const int i = i0 + u;
-                if (i < boundu) {
-                  const int j = jc;
-                  jc = jc + 1 == memu ? 0 : jc + 1;
-                  const double av = alpha[j];
-                  double part = 0.0;
-#pragma unroll
-                  for (int t = 0; t < EPL; t++) part = fma(yb[u][t], dr[t], part);
-                  const double beta = wsum(part) * rb[u];
-                  const double co = av - beta;
-#pragma unroll
-                  for (int t = 0; t < EPL; t++) dr[t] = fma(co, sb[u][t], dr[t]);
-                }
+                step2(u, i0 + u);
                 load_pair(u, jl);
                 jl = jl + 1 == memu ? 0 : jl + 1;
               }
             }
+#pragma unroll
+            for (int u = 0; u < PF - 1; u++)
+              if (i0 + u < boundu) step2(u, i0 + u);
             vec_store<EPL, NT>(S.d, n, tid, dr);
             SUBSTAMP_END(C, 10);  // two-loop recursion
           }
