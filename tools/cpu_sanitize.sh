@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd $ROOT/tests/emu
-FLAGS="-O1 -g -std=c++17 -fPIC -march=x86-64-v3 -ffp-contract=off -DTOPAY_LDS= -DTOPAY_GLB= -shared -x c++ -I include"
+FLAGS="-O1 -g -std=c++17 -fPIC -march=x86-64-v3 -ffp-contract=off -DTOPAY_LDS= -DTOPAY_GLB= -DTOPAY_CST= -shared -x c++ -I include"
 g++ $FLAGS -fsanitize=undefined -fno-sanitize-recover=undefined -o /tmp/libtopay_emu_ubsan.so ../../topay_amd/csrc/topay_hip.hip
 g++ $FLAGS -fsanitize=address -fno-omit-frame-pointer -o /tmp/libtopay_emu_asan.so ../../topay_amd/csrc/topay_hip.hip
 cd $ROOT

@@ -30,6 +30,20 @@
 // Optimizer/robot parameters live in constant memory: every access is a scalar load the compiler can re-issue at
 // the point of use instead of keeping hundreds of SGPRs of kernel arguments alive across the whole solve.
 __constant__ DevParams g_P;
+// The parameter block through ONE base address per function, held in a scalar register pair: the compiler otherwise forms the
+// address of every field it reads from the program counter anew (s_getpc_b64 + 64-bit add: three scalar instructions ahead of
+// each of the 133 parameter loads of the manipulator block -- a wave issues one instruction per four cycles whatever its kind).
+// The empty asm hides where the pointer comes from, so the fields become immediate offsets from it.
+typedef const TOPAY_CST DevParams& dev_params_ref;
+__device__ __forceinline__ dev_params_ref dev_params() {
+#ifndef TOPAY_CPU_EMU
+  const TOPAY_CST DevParams* p = (const TOPAY_CST DevParams*)&g_P;
+  asm("" : "+s"(p));
+  return *p;
+#else
+  return g_P;
+#endif
+}
 
 // Optional scheduling fences between the independent sub-blocks of the manipulator block (off: a leftover of rounds 1-2;
 // every kernel is built for 256 registers since round 4 and the block's sphere loop carries its own fence, TOPAY_OCC2_FENCE).
@@ -228,8 +242,7 @@ __device__ __forceinline__ double dQdVq(double vq, double max_q) {
   return 2.0 * max_q * dTdTau(vq) / (e1 * e1);
 }
 // smoothL1Penalty, only meaningful for x > 0 — moma_traj_opt.h:810-830 (constants precomputed in DevParams)
-__device__ __forceinline__ void smoothL1(double x, double mu, double& f, double& df) {
-  const DevParams& P = g_P;
+__device__ __forceinline__ void smoothL1(dev_params_ref P, double x, double mu, double& f, double& df) {
   if (x < mu) {
     f = (P.sl_f4c * x + P.sl_f3c) * x * x * x;
     df = (P.sl_d3c * x + P.sl_d2c) * x * x;
@@ -793,9 +806,10 @@ __device__ long long g_mani_stamps[8];
 template <int OCC>
 __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, lds_cdp cL, int rows, int pi, int pj, double half, double step,
                                                   double posx, double posy, int e, glb_dp mstash, lds_dp mg_lds) {
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   const DevMap M = load_map(mp);
   const bool in_act = e >= 0;
+  const double invK = topay_hold_f64(TOPAY_INV_K), ten = topay_hold_f64(10.0);
   const glb_dp in_stash = mstash + 36 * (in_act ? e : 0);
   // pose of the sample: order-0 polynomials of theta and the seven joints (the arc length is not part of the pose), in the
   // arithmetic of poly4 / make_basis
@@ -811,7 +825,6 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
       lds_cdp c = cL + d * rows + 6 * pi;
       pos[d == 0 ? 2 : d + 1] = fma(c[5], s5, fma(c[4], s4, fma(c[3], s3, fma(c[2], s2, fma(c[1], s1, c[0])))));
     }
-    det_sincos(pos[2], &sth, &cth);
   }
   const double omg = (pj == 0 || pj == 2 * TOPAY_K) ? 0.5 : 1.0;
   ManiOut out;
@@ -822,12 +835,17 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
   long long mt_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
   double sq[7], cq[7];
+  {
+    // yaw and the seven joints, step by step across the eight angles (det_sincos_n: the constants of a step are formed once)
+    double ang[8], sn8[8], cs8[8];
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
-    det_sincos(pos[3 + i], &sq[i], &cq[i]);
-    TOPAY_SCHED_FENCE();
+    for (int i = 0; i < 8; i++) ang[i] = pos[2 + i];
+    det_sincos_n<8>(ang, sn8, cs8);
+    sth = sn8[0]; cth = cs8[0];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { sq[i] = sn8[1 + i]; cq[i] = cs8[1 + i]; }
   }
-  MSTAMP(0);  // 7 sincos
+  MSTAMP(0);  // 8 sincos
   MMARK(0);
   double A[9];
   {
@@ -915,7 +933,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
             const double dist = P.pair_rr2[a * TOPAY_NSPH + b] - fma(dz, dz, fma(dy, dy, dx * dx));
             if (dist > 0) {
               double pe, pd;
-              smoothL1(dist, mu, pe, pd);
+              smoothL1(P, dist, mu, pe, pd);
               const double sc = -w * wSC * pd * 2.0;
               sg[3 * a + 0] = fma(sc, dx, sg[3 * a + 0]);
               sg[3 * a + 1] = fma(sc, dy, sg[3 * a + 1]);
@@ -923,7 +941,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
               sg[3 * b + 0] = fma(-sc, dx, sg[3 * b + 0]);
               sg[3 * b + 1] = fma(-sc, dy, sg[3 * b + 1]);
               sg[3 * b + 2] = fma(-sc, dz, sg[3 * b + 2]);
-              gdTk += omg * wSC * (pe * TOPAY_INV_K);
+              gdTk += omg * wSC * (pe * invK);
               cost += w * wSC * pe;
             }
           }
@@ -952,9 +970,9 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
       const double height = P.sph_top[k] - Pz[k];
       if (height > 0) {
         double pe, pd;
-        smoothL1(height, mu, pe, pd);
+        smoothL1(P, height, mu, pe, pd);
         Gz += -w * wSC * pd;
-        gdTk += omg * wSC * (pe * TOPAY_INV_K);
+        gdTk += omg * wSC * (pe * invK);
         cost += w * wSC * pe;
       }
     }
@@ -974,13 +992,13 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
     }
 #endif
     esdf3d_finish(M, rq[k % (LA + 1)], d, gx, gy, gz);
-    const double viola = P.sph_viol[k] - d * 10.0;
+    const double viola = P.sph_viol[k] - d * ten;
     if (viola > 0) {
       double pe, pd;
-      smoothL1(viola, mu, pe, pd);
+      smoothL1(P, viola, mu, pe, pd);
       const double sc = -w * wMC * pd;
-      Gx += sc * gx * 10.0; Gy += sc * gy * 10.0; Gz += sc * gz * 10.0;
-      gdTk += omg * wMC * (pe * TOPAY_INV_K);
+      Gx += sc * gx * ten; Gy += sc * gy * ten; Gz += sc * gz * ten;
+      gdTk += omg * wMC * (pe * invK);
       cost += w * wMC * pe;
     }
     bFx += Gx;
@@ -1063,17 +1081,17 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
     double v = pos[ji + 3] - P.joint_pos_limit_max[ji];
     if (v > 0) {
       double pe, pd;
-      smoothL1(v, mu, pe, pd);
+      smoothL1(P, v, mu, pe, pd);
       mg_lds[ji * 64] += w * wJP * pd;
-      gdTk += omg * wJP * (pe * TOPAY_INV_K);
+      gdTk += omg * wJP * (pe * invK);
       cost += w * wJP * pe;
     }
     v = -P.joint_pos_limit_max[ji] - pos[ji + 3];
     if (v > 0) {
       double pe, pd;
-      smoothL1(v, mu, pe, pd);
+      smoothL1(P, v, mu, pe, pd);
       mg_lds[ji * 64] -= w * wJP * pd;
-      gdTk += omg * wJP * (pe * TOPAY_INV_K);
+      gdTk += omg * wJP * (pe * invK);
       cost += w * wJP * pe;
     }
   }
@@ -1090,7 +1108,7 @@ __device__ __noinline__ ManiOut manipulator_block(const TOPAY_GLB DevMap* mp, ld
 // kinodynamic penalties shared by both stages — moma_traj_opt.cpp:1059-1115 / 1334-1462.
 // th1,th2,th3 = theta', theta'', theta'''; s1..s3 likewise.  Adds to cost, gdT and the gradBeta entries
 // (gth1 = d/d theta', gth2 = d/d theta'', gs1, gs2).
-__device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM, double wA, double wD, double omg,
+__device__ __forceinline__ void kinodynamic_block(dev_params_ref P, double wM, double wA, double wD, double omg,
                                                   double step, double real_alpha, double th1, double th2, double th3,
                                                   double sd1, double sd2, double sd3, double& cost, double& gdT,
                                                   double& gth1, double& gth2, double& gs1, double& gs2) {
@@ -1102,7 +1120,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
     const double v = sgn * max_v * th1 + max_w * sd1 - P.max_vw;
     if (v > 0) {
       double pe, pd;
-      smoothL1(v, mu, pe, pd);
+      smoothL1(P, v, mu, pe, pd);
       const double gt = real_alpha * (sgn * max_v * th2 + max_w * sd2);
       gth1 += w * wM * pd * sgn * max_v;
       gs1 += w * wM * pd * max_w;
@@ -1115,7 +1133,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
     const double v = sgn * max_v * th1 - max_w * sd1 - P.max_vw;
     if (v > 0) {
       double pe, pd;
-      smoothL1(v, mu, pe, pd);
+      smoothL1(P, v, mu, pe, pd);
       const double gt = real_alpha * (sgn * max_v * th2 - max_w * sd2);
       gth1 += w * wM * pd * sgn * max_v;
       gs1 -= w * wM * pd * max_w;
@@ -1127,7 +1145,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
   const double vAlp = th2 * th2 - P.max_dw2;
   if (vAcc > 0) {
     double pe, pd;
-    smoothL1(vAcc, mu, pe, pd);
+    smoothL1(P, vAcc, mu, pe, pd);
     const double gt = 2.0 * real_alpha * sd2 * sd3;
     gs2 += w * wA * pd * 2.0 * sd2;
     gdT += omg * wA * (pd * gt * step + pe * TOPAY_INV_K);
@@ -1135,7 +1153,7 @@ __device__ __forceinline__ void kinodynamic_block(const DevParams& P, double wM,
   }
   if (vAlp > 0) {
     double pe, pd;
-    smoothL1(vAlp, mu, pe, pd);
+    smoothL1(P, vAlp, mu, pe, pd);
     const double gt = 2.0 * real_alpha * th2 * th3;
     gth2 += w * wD * pd * 2.0 * th2;
     gdT += omg * wD * (pd * gt * step + pe * TOPAY_INV_K);
@@ -1183,10 +1201,9 @@ __device__ __forceinline__ ManiOut sample_mani(lds_cdp cL, int rows, int i, int 
 }
 
 template <int STAGE>
-__device__ __forceinline__ void sample_rest(lds_cdp cL, int rows, int i, int j, double step, double half, double posx, double posy,
+__device__ __forceinline__ void sample_rest(dev_params_ref P, lds_cdp cL, int rows, int i, int j, double step, double half, double posx, double posy,
                                             const TOPAY_GLB DevMap* mp, double wM, double wA, double wD, const ManiOut& mo_, lds_cdp mg_lds,
                                             double (&gB)[12], double& gdTs, double& gpx, double& gpy, bool& jva, double& cst) {
-  const DevParams& P = g_P;
 #pragma unroll
   for (int v = 0; v < 12; v++) gB[v] = 0.0;
   gdTs = 0.0; gpx = 0.0; gpy = 0.0;
@@ -1211,7 +1228,7 @@ __device__ __forceinline__ void sample_rest(lds_cdp cL, int rows, int i, int j, 
     const double viola = P.chassis_r105 - d2;
     if (viola > 0) {
       double pe, pd;
-      smoothL1(viola, P.relu_mu, pe, pd);
+      smoothL1(P, viola, P.relu_mu, pe, pd);
       const double sc = -omg * step * P.s2_collision_weight * pd;
       gpx += sc * g2x;
       gpy += sc * g2y;
@@ -1229,14 +1246,14 @@ __device__ __forceinline__ void sample_rest(lds_cdp cL, int rows, int i, int j, 
       const double vD2q = a2 * a2 - P.joint_acc_limit2[q];
       if (vDq > 0) {
         double pe, pd;
-        smoothL1(vDq, P.relu_mu, pe, pd);
+        smoothL1(P, vDq, P.relu_mu, pe, pd);
         gdTs += omg * P.s2_mani_vel_weight * (pd * (2.0 * real_alpha * a1 * a2) * step + pe * TOPAY_INV_K);
         cst += omg * step * P.s2_mani_vel_weight * pe;
         jva = true;
       }
       if (vD2q > 0) {
         double pe, pd;
-        smoothL1(vD2q, P.relu_mu, pe, pd);
+        smoothL1(P, vD2q, P.relu_mu, pe, pd);
         gdTs += omg * P.s2_mani_acc_weight * (pd * (2.0 * real_alpha * a2 * a3) * step + pe * TOPAY_INV_K);
         cst += omg * step * P.s2_mani_acc_weight * pe;
         jva = true;

@@ -130,7 +130,7 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   const glb_cdp c_hd = C.hd, c_tl = C.tl;   // head / tail PVA, 9 x 3 col-major each (HBM: read once per evaluation)
   const glb_dp c_lu = C.lu;
   const glb_cdp c_x = C.x;
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   const int tid = C.tid, lane = C.lane, wave = __builtin_amdgcn_readfirstlane(C.wave);
   const int N = __builtin_amdgcn_readfirstlane(C.N), rows = __builtin_amdgcn_readfirstlane(C.rows);
   lds_dp cL = C.cL;
@@ -289,7 +289,7 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
   const lds_dp c_adj = uniform_ptr(C.adj);
   const glb_dp c_coefg = uniform_ptr(C.coefg);
 
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   // (lane and tid are formed again after every call of the manipulator block -- fresh_lane_id -- instead of being kept
   // across it: what a lane holds in vector registers across the call goes through scratch memory)
   int lane = C.lane, tid = C.tid;
@@ -438,7 +438,7 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
         }
         double gB[12], gdTs, gpx, gpy, cst;
         bool jva;
-        sample_rest<STAGE>(cL, rows, i, j, step, half, posx, posy, mp, wM, wA, wD, mo, pbuf + lane, gB, gdTs, gpx, gpy, jva, cst);
+        sample_rest<STAGE>(P, cL, rows, i, j, step, half, posx, posy, mp, wM, wA, wD, mo, pbuf + lane, gB, gdTs, gpx, gpy, jva, cst);
         if (act) {
           cst_out = cst;
           gxy[2 * e] = gpx;
@@ -685,12 +685,12 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
               const double vD2q = p2 * p2 - P.joint_acc_limit2[q];
               if (vDq > 0) {
                 double pe, pd;
-                smoothL1(vDq, P.relu_mu, pe, pd);
+                smoothL1(P, vDq, P.relu_mu, pe, pd);
                 g1[q] = omg * step * P.s2_mani_vel_weight * pd * 2.0 * p1;
               }
               if (vD2q > 0) {
                 double pe, pd;
-                smoothL1(vD2q, P.relu_mu, pe, pd);
+                smoothL1(P, vD2q, P.relu_mu, pe, pd);
                 g2[q] = omg * step * P.s2_mani_acc_weight * pd * 2.0 * p2;
               }
             }
@@ -830,12 +830,12 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
             const double vD2q = p2 * p2 - P.joint_acc_limit2[qq];
             if (vDq > 0) {
               double pe, pd;
-              smoothL1(vDq, P.relu_mu, pe, pd);
+              smoothL1(P, vDq, P.relu_mu, pe, pd);
               g1 = omg * step * P.s2_mani_vel_weight * pd * 2.0 * p1;
             }
             if (vD2q > 0) {
               double pe, pd;
-              smoothL1(vD2q, P.relu_mu, pe, pd);
+              smoothL1(P, vD2q, P.relu_mu, pe, pd);
               g2 = omg * step * P.s2_mani_acc_weight * pd * 2.0 * p2;
             }
             pbuf[qq * 64 + lane] = g1;

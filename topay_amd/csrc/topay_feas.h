@@ -96,7 +96,7 @@ __device__ __forceinline__ double feas_dist3d(const DevMap& M, double px, double
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
 __device__ __forceinline__ void feasibility_gate(const FeasIO& F, const TOPAY_GLB DevMap* mp) {
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   const int lane = threadIdx.x & 63;
   const int N = F.N, rows = 6 * N;
   const DevMap M = load_map(mp);
@@ -353,7 +353,7 @@ __device__ __forceinline__ void playback(const FeasIO& F, int nq, const double* 
 // (isCollision2d / isCollision3d, grid_map.h:511-536, 699-725).  One thread per state.
 // MomaParam::getColliPts (moma_param.h:203-247): centres of the 12 collision spheres of state st = (x, y, theta, q1..q7)
 __device__ __forceinline__ void sphere_centres(const double* st, double (&Px)[TOPAY_NSPH], double (&Py)[TOPAY_NSPH], double (&Pz)[TOPAY_NSPH]) {
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   double sq[7], cq[7], sth, cth;
 #pragma unroll
   for (int q = 0; q < 7; q++) det_sincos(st[3 + q], &sq[q], &cq[q]);
@@ -393,7 +393,7 @@ __device__ __forceinline__ void sphere_centres(const double* st, double (&Px)[TO
 }
 
 __device__ __forceinline__ bool whole_body_collision(const DevMap& M, const double* st) {
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   bool hit = false;
 #pragma unroll
   for (int q = 0; q < 7; q++) hit = hit || st[3 + q] > P.joint_pos_limit_max[q] || st[3 + q] < -P.joint_pos_limit_max[q];
@@ -480,7 +480,7 @@ __device__ __forceinline__ void mq_matmul(const double (&a)[9], const double (&b
     for (int j = 0; j < 3; j++) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
 }
 __device__ __forceinline__ void mesh_pose(const topay_mesh_params_t& K, const double* st, double* out /* 11 x 7 */) {
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   auto put = [&](int r, double px, double py, double pz, const MeshQuat& q) {
     double* o = out + 7 * r;
     o[0] = px; o[1] = py; o[2] = pz; o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;

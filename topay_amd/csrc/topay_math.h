@@ -57,6 +57,136 @@ __device__ __forceinline__ void det_sincos(double x, double* sn, double* cs) {
   *cs = bad ? nanv : co;
 }
 
+// sin and cos of NA angles, step by step across the angles: the arithmetic of an angle is that of det_sincos (same
+// operations, same order), but each of the seventeen 64-bit constants is then live for NA adjacent instructions instead of
+// being formed anew for every angle (f64 instructions of gfx950 take no 64-bit literal: two scalar moves per use; the
+// manipulator block takes eight sines and cosines per sample).
+// A 64-bit constant held in a scalar register pair (the empty asm hides that it is a constant, so it cannot be formed anew
+// at each use -- two s_mov_b32 each time, since f64 instructions of gfx950 take no 64-bit literal).
+__device__ __forceinline__ double topay_hold_f64(double v) {
+#ifndef TOPAY_CPU_EMU
+  asm("" : "+s"(v));
+#endif
+  return v;
+}
+// keeps the machine scheduler from undoing the step-by-step order below (it would rather finish one angle at a time)
+#ifndef TOPAY_CPU_EMU
+#define TOPAY_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TOPAY_STEP_FENCE() do { } while (0)
+#endif
+template <int NA>
+__device__ __forceinline__ void det_sincos_n(const double (&xin)[NA], double (&sn)[NA], double (&cs)[NA]) {
+  // (held in scalar register pairs, topay_hold_f64: the compiler forms a 64-bit constant anew at every use otherwise)
+  const double invpio2 = topay_hold_f64(6.36619772367581382433e-01), pio2_1 = topay_hold_f64(1.57079632673412561417e+00),
+               pio2_2 = topay_hold_f64(6.07710050630396597660e-11), pio2_2t = topay_hold_f64(2.02226624879595063154e-21);
+  const double S1 = topay_hold_f64(-1.66666666666666324348e-01), S2 = topay_hold_f64(8.33333333332248946124e-03),
+               S3 = topay_hold_f64(-1.98412698298579493134e-04), S4 = topay_hold_f64(2.75573137070700676789e-06),
+               S5 = topay_hold_f64(-2.50507602534068634195e-08), S6 = topay_hold_f64(1.58969099521155010221e-10);
+  const double C1 = topay_hold_f64(4.16666666666666019037e-02), C2 = topay_hold_f64(-1.38888888888741095749e-03),
+               C3 = topay_hold_f64(2.48015872894767294178e-05), C4 = topay_hold_f64(-2.75573143513906633035e-07),
+               C5 = topay_hold_f64(2.08757232129817482790e-09), C6 = topay_hold_f64(-1.13596475577881948265e-11);
+  bool bad[NA];
+  double fn[NA], y0[NA], y1[NA];
+  {
+    double xs[NA], t[NA], w[NA], r[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) { bad[a] = !(fabs(xin[a]) < 1.0e15); xs[a] = bad[a] ? 0.0 : xin[a]; }
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) fn[a] = rint(xs[a] * invpio2);
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) t[a] = xs[a] - fn[a] * pio2_1;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) w[a] = fn[a] * pio2_2;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) r[a] = t[a] - w[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) w[a] = fn[a] * pio2_2t - ((t[a] - r[a]) - w[a]);
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) { y0[a] = r[a] - w[a]; y1[a] = (r[a] - y0[a]) - w[a]; }
+    TOPAY_STEP_FENCE();
+  }
+  double s[NA], c[NA];
+  {
+    // k_sin(y0, y1):  r = S2 + z (S3 + z S4) + z w (S5 + z S6);  v = z x;  x - ((z (0.5 y - v r) - y) - v S1)
+    double z[NA], p[NA], q[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) z[a] = y0[a] * y0[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = z[a] * S4;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = S3 + p[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = S2 + z[a] * p[a];            // S2 + z (S3 + z S4)
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) q[a] = z[a] * S6;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) q[a] = S5 + q[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+      const double w = z[a] * z[a];
+      const double r = p[a] + z[a] * w * q[a];
+      const double v = z[a] * y0[a];
+      p[a] = (z[a] * (0.5 * y1[a] - v * r) - y1[a]);
+      q[a] = v;
+    }
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) s[a] = y0[a] - (p[a] - q[a] * S1);
+    TOPAY_STEP_FENCE();
+    // k_cos(y0, y1):  r = z (C1 + z (C2 + z C3)) + (w0 w0) (C4 + z (C5 + z C6));  hz = 0.5 z;  w = 1 - hz;
+    //                 w + (((1 - w) - hz) + (z r - x y))
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = z[a] * C3;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = C2 + p[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) p[a] = C1 + z[a] * p[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) q[a] = z[a] * C6;
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) q[a] = C5 + q[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) q[a] = C4 + z[a] * q[a];
+    TOPAY_STEP_FENCE();
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+      const double w0 = z[a] * z[a];
+      const double r = z[a] * p[a] + (w0 * w0) * q[a];
+      const double hz = 0.5 * z[a];
+      const double w = 1.0 - hz;
+      c[a] = w + (((1.0 - w) - hz) + (z[a] * r - y0[a] * y1[a]));
+    }
+    TOPAY_STEP_FENCE();
+  }
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+  for (int a = 0; a < NA; a++) {
+    const int n = (int)((long long)fn[a] & 3);
+    const double so = (n == 0) ? s[a] : (n == 1) ? c[a] : (n == 2) ? -s[a] : -c[a];
+    const double co = (n == 0) ? c[a] : (n == 1) ? -s[a] : (n == 2) ? -c[a] : s[a];
+    sn[a] = bad[a] ? nanv : so;
+    cs[a] = bad[a] ? nanv : co;
+  }
+}
+
 __device__ __forceinline__ double det_atan(double xin) {
   const double aT[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,
                          -1.11111104054623557880e-01, 9.09088713343650656196e-02,  -7.69187620504482999495e-02,

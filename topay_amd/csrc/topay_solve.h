@@ -146,7 +146,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
                                                  double& cost_out, int& interrupted_out) {
   static_assert(NWE == NW || NW == 1, "helper waves join a one-wave solver");
   constexpr bool HELPERS = NWE != NW;
-  const DevParams& P = g_P;
+  dev_params_ref P = dev_params();
   constexpr int NT = 64 * NW;    // threads that run the solver
   // barrier among the solver's threads (with helper waves: wave 0 alone -- no workgroup barrier outside the hand-shake)
   auto ssync = [&]() {

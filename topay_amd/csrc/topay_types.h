@@ -26,6 +26,13 @@
 #ifndef TOPAY_GLB
 #define TOPAY_GLB __attribute__((address_space(1)))
 #endif
+#ifndef TOPAY_CST
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOPAY_CST __attribute__((address_space(4)))   // constant memory (the parameter block): scalar loads
+#else
+#define TOPAY_CST                                     // (host pass of the same sources: the qualifier means nothing there)
+#endif
+#endif
 typedef TOPAY_LDS double* lds_dp;
 typedef const TOPAY_LDS double* lds_cdp;
 typedef TOPAY_GLB double* glb_dp;
