@@ -205,17 +205,25 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   // LU without pivoting on wave 0 (banded_system.hpp:66-91); the other waves wait at the barrier below
   if (wave == 0) {
     const int t = lane / 7 + 1, u = lane - (lane / 7) * 7;
+    // BAND(a, b) = band[(a - b + 6) rows + b]: the four entries a lane reads at pivot k are lane constants + k.  Lanes 42..63
+    // read the pivot itself; a lane whose row or column lies beyond the matrix (the last six pivots) reads some other entry
+    // of the band and writes nothing.
+    const bool lane_in = lane < 42;
+    const int o_kk = 6 * rows;
+    const int o_ik = lane_in ? (t + 6) * rows : o_kk;
+    const int o_ij = lane_in ? (t - u + 6) * rows + u : o_kk;
+    const int o_kj = lane_in ? (6 - u) * rows + u : o_kk;
     for (int k = 0; k <= rows - 2; k++) {
       const int i = k + t, j = k + u;
-      const bool act = (lane < 42) && (i < rows) && (j < rows);
-      double nv = 0.0;
-      if (act) {
-        const double akk = BAND(k, k), aik = BAND(i, k);
-        const double m = aik / akk;
-        nv = (u == 0) ? m : (BAND(i, j) - m * BAND(k, j));
-      }
+      const bool act = lane_in && (i < rows) && (j < rows);
+      // all four reads are issued ahead of the division: one LDS round trip per pivot instead of two, and no branch around
+      // the multiply-subtract
+      double akk = band[o_kk + k], aik = band[o_ik + k], aij = band[o_ij + k], akj = band[o_kj + k];
+      TOPAY_OPAQUE(aij); TOPAY_OPAQUE(akj);   // (or the compiler moves these two reads back behind the division)
+      const double m = aik / akk;
+      const double nv = (u == 0) ? m : (aij - m * akj);
       lds_sync();
-      if (act) BAND(i, j) = nv;
+      if (act) band[o_ij + k] = nv;
       lds_sync();
     }
   }
