@@ -42,6 +42,16 @@ __device__ __forceinline__ void wg_barrier() {
   else wg_lds_barrier();
 }
 
+// Hand-off through GLOBAL memory (stores by some threads, loads by others).  One wave: the memory instructions of a wave are
+// performed in issue order, lanes or no lanes, so only the compiler has to be kept from reordering -- no wait for the stores to
+// come back (a round trip to L2 / HBM each time: the LU stash, the coefficients' move to the result block and the gradient at
+// the end of every evaluation).  Several waves: the full barrier.
+template <int NW>
+__device__ __forceinline__ void wg_global_barrier() {
+  if (NW == 1) lds_sync();
+  else __syncthreads();
+}
+
 // Sum over the workgroup in a fixed order: wave tree (wave_sum), then (w0 + w1) + (w2 + w3).  `red` holds two sets of
 // four partial sums used alternately, so one barrier per reduction suffices (a wave can only write a set again after
 // every wave has passed the barrier that follows the reads of its previous use); `phase` is a workgroup-uniform local
@@ -233,8 +243,8 @@ __device__ __noinline__ void minco_generate_mw(EvalCtx& C) {
   wg_barrier<NW>();
   // factors to the candidate's LU block; nothing of the band is read from LDS after this
   for (int t = tid; t < 14 * rows; t += NT) c_lu[t] = band[t];
-  wave_global_sync();
-  wg_barrier<NW>();
+  if (NW == 1) lds_sync();   // (wg_global_barrier: the sweeps below read the factors back on this wave)
+  else { wave_global_sync(); wg_barrier<NW>(); }
   // right-hand sides over the band: boundary conditions and inner points, zero elsewhere
   for (int t = tid; t < 9 * rows; t += NT) cL[t] = 0.0;
   wg_barrier<NW>();
@@ -1043,7 +1053,7 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
   // is where a solve that ends here leaves them anyway); the dJ/dT correction below reads them back from there
   for (int t = tid; t < 9 * rows; t += NT) c_coefg[t] = cL[t];
   C.cl_in_lds = 0;
-  __syncthreads();
+  wg_global_barrier<NW>();
   // (the LU factors stream from the candidate's LU block through the windows of band_sweep: nothing to reload)
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -1112,7 +1122,7 @@ __device__ __noinline__ TOPAY_CALLS_BIG_FUNCTIONS double eval_cost_grad_mw(EvalC
     else c_g[3 * N - 1 + 7 * i + dq] = gp * dQdVq(Vq[7 * i + dq], P.joint_pos_limit_max[dq]);
   }
   if (tid == 0) c_g[3 * N - 2] = c_adj[1 * rows + rows - 3];
-  __syncthreads();
+  wg_global_barrier<NW>();
   STAMP(C, 8);  // dJ/dT correction, chain rule
   return f_total;
 }
