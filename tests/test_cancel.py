@@ -198,9 +198,11 @@ def test_wall_clock_budget_interrupts_what_has_not_finished():
     assert not timed_out and (ok_gen == ok_full).all() and np.array_equal(np.nan_to_num(gpu.traj_cost), np.nan_to_num(cost_full))
     assert not gpu.interrupted().any()
     gpu.reset()
-    ok_short, timed_out = gpu.optimize_within(max(1.0, 0.15 * ms_full))
+    # (a tenth of the full solve: the full time is the longest candidate's, and the faster the long candidates got relative to
+    # the rest -- the two-loop recursion of round 5 -- the fewer are still running at a fixed fraction of it: 0.15 left 29.9 %)
+    ok_short, timed_out = gpu.optimize_within(max(1.0, 0.10 * ms_full))
     intr = gpu.interrupted().astype(bool)
-    print(f"full solve {ms_full:.0f} ms; budget {0.15 * ms_full:.0f} ms: {int(intr.sum())} of {len(intr)} interrupted, {int(ok_short.sum())} succeeded in time")
+    print(f"full solve {ms_full:.0f} ms; budget {0.10 * ms_full:.0f} ms: {int(intr.sum())} of {len(intr)} interrupted, {int(ok_short.sum())} succeeded in time")
     assert timed_out and intr.sum() > 0.3 * len(intr)
     assert not (ok_short & intr).any()
     done = ok_short & ~intr
