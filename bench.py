@@ -514,7 +514,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per step (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "k_solve1/2/3 + k_long5/10 (persistent solve: one workgroup of 1 or 4 waves per trajectory takes candidates from its class's queue; the "
+            "kernel": "k_solve1/2/3 + k_long5/14 (persistent solve: one workgroup of 1 or 4 waves per trajectory takes candidates from its class's queue; the "
                       "up to six class launches of a batch run concurrently; the long classes solve on one wave and evaluate on four)",
             "kernel_ms": kms,
             "kernel_ms_definition": kdef,
