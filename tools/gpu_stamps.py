@@ -4,7 +4,7 @@ import numpy as np
 from harness import workload as wl
 from topay_amd import api
 gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB", "topay_amd/lib/libtopay_hip_stamps.so"))
-names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "rows+sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]
+names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "rows+sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(state read back)", "(trial / accepted it. incl. twoloop)", "(ls prologue)", "(-)", "(poll, barrier, park)"]
 for S in (int(sys.argv[1]) if len(sys.argv) > 1 else 128,):
     w2, lens2, paths2, scen2 = wl.cuboids_batch(S, 8)
     gpu.set_map(w2.origin, w2.res, w2.dims, w2.min_b, w2.max_b, w2.esdf2d, w2.esdf3d)

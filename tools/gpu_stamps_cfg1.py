@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from harness import workload as wl
 from topay_amd import api
-names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "rows+sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(s1 rounds)", "(body)", "(mani)", "(adj sweeps)", "(s1 merged round)"]
+names = ["fill", "LU", "subst", "jerk", "sweep1", "between", "rows+sweep2", "adjoint", "assemble", "lbfgs", "(twoloop)", "(state read back)", "(trial / accepted it. incl. twoloop)", "(ls prologue)", "(-)", "(poll, barrier, park)"]
 w1, _, _, lens1, paths1 = wl.tables_scenario(0, 64)
 for mode in (0, 1):
     gpu = api.MomaTrajOptBatch(device=0, lib_path=os.environ.get("TOPAY_LIB", "tools/libs/libtopay_stamps.so"))

@@ -140,6 +140,18 @@ __device__ __forceinline__ void eval_helper_loop(EvalCtx& C, const TOPAY_GLB Dev
   }
 }
 
+// diagnostics build: where the solver's time between two evaluations goes (slots 11..15 of the stamp block; the phase clock of
+// STAMP is left alone).  This is how the host-memory poll below was found.
+#ifdef TOPAY_STAMPS
+#define LSTAMP(k)                                                                              \
+  do {                                                                                         \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();                            \
+    if (C.stamps && C.lane == 0) C.stamps[k] += now_ - lt_;                                    \
+    lt_ = (long long)__builtin_amdgcn_s_memtime();                                             \
+  } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
 template <int RMAX, int NW = 1, int OCC = 2, int NWE = NW, int RMAX_E = RMAX>
 __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB DevMap* mp, SolveIO& S, int s1_past,
                                                  lds_dp pf /* LDS [8 + 40], then the command block if NWE != NW */, int& success_out,
@@ -186,6 +198,13 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
   double cost = 0.0;
   int ntrace = 0;
 
+  // topay_cancel's flag lives in pinned HOST memory: reading it is a round trip over the bus (2-3 us, and a wave's loads return
+  // in order, so the next vector load waits for it whatever lies between).  Read at every evaluation it cost 8-12k cycles of each,
+  // 3 % of a solve; it is read at every eighth (every fourth / every one for candidates of more than 16 / 32 pieces, whose
+  // evaluations are long): a cancelled call comes back within a millisecond or two all the same.
+#ifdef TOPAY_STAMPS
+  long long lt_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     const DevLbfgs& lp = stage == 1 ? P.s1_lbfgs : P.s2_lbfgs;
     const int past = stage == 1 ? s1_past : lp.past;
@@ -197,12 +216,13 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       int stop = 0;
       if (tid == 0) {
         const int clock = (st_s1_ev + st_s2_ev + evals) * C.N;   // piece-evaluations done so far
+        const int poll_mask = C.N <= 16 ? 7 : (C.N <= 32 ? 3 : 0);
 #ifndef TOPAY_CPU_EMU
         if (S.grp_tau) stop = (long long)clock > (long long)__hip_atomic_load(S.grp_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + S.cancel_budget;
-        if (S.cancel_flag) stop |= __hip_atomic_load(S.cancel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        if (S.cancel_flag && (evals & poll_mask) == 0) stop |= __hip_atomic_load(S.cancel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
 #else
         if (S.grp_tau) stop = (long long)clock > (long long)*S.grp_tau + S.cancel_budget;
-        if (S.cancel_flag) stop |= *S.cancel_flag != 0;
+        if (S.cancel_flag && (evals & poll_mask) == 0) stop |= *S.cancel_flag != 0;
 #endif
       }
       if constexpr (NW == 1) {
@@ -268,8 +288,12 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       ic[0] = 1; ic[1] = stage; ic[2] = gate.always ? 1 : 0; ic[3] = gate.has_early ? 1 : 0; ic[4] = gate.early_ok ? 1 : 0;
       __syncthreads();   // the helper waves wait here (eval_helper_loop); x written above is visible to them
     }
+    LSTAMP(15);   // interruption poll, barrier, state parked
     if (stage == 1) f = eval_cost_grad_mw<1, RMAX_E, NWE, OCC>(C, mp, gate);
     else f = eval_cost_grad_mw<2, RMAX_E, NWE, OCC>(C, mp, gate);
+#ifdef TOPAY_STAMPS
+    lt_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (NWE > 1) wg_lds_barrier();   // every wave is out of the evaluation's last reduction before the scratch is used again
     rp = 0;
     {
@@ -300,6 +324,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       f = uniform_f64(f);
     }
     evals++;
+    LSTAMP(11);   // state read back
 #ifndef TOPAY_STAMPS
     if (S.trace && tid == 0 && ntrace < S.trace_cap) S.trace[ntrace] = f;
 #endif
@@ -578,6 +603,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
 
+    LSTAMP(12);   // first point / line-search trial / accepted iteration (with the two-loop recursion, slot 10)
     if (go == GO_LS_BEGIN) {
       // lbfgs.hpp:559-573 + line-search prologue 288-311
       {
@@ -619,6 +645,7 @@ __device__ __forceinline__ void solve_trajectory(EvalCtx& C, const TOPAY_GLB Dev
       }
     }
 
+    LSTAMP(13);   // line-search prologue
     if (go == GO_RUN_END) {
       cost = fx;
       const bool okret = (ret == TOPAY_LBFGS_CONVERGENCE || ret == TOPAY_LBFGS_CANCELED || ret == TOPAY_LBFGS_STOP ||
