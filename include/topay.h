@@ -441,8 +441,10 @@ topay_status topay_test_math(topay_ctx* ctx, int n, const double* a, const doubl
  * Call after topay_set_init_traj (a new batch starts without groups). */
 #define TOPAY_INTERRUPTED (-2000)
 topay_status topay_set_groups(topay_ctx* ctx, const int* group_id /* batch */, int cancel_budget);
-/* threads.interrupt_all() (planner.cpp:952) for the solve in flight: every candidate stops at its next interruption
- * point.  Returns at once (callable from another thread than the one in topay_synchronize). */
+/* threads.interrupt_all() (planner.cpp:952) for the solve in flight: every candidate stops at one of its next interruption
+ * points (the flag lives in host memory; a running candidate looks at it ahead of every eighth stage-2 evaluation -- every
+ * fourth / every one with more than 16 / 32 pieces -- i.e. within a millisecond or two; a workgroup before it takes another
+ * candidate).  Returns at once (callable from another thread than the one in topay_synchronize). */
 topay_status topay_cancel(topay_ctx* ctx);
 topay_status topay_get_interrupted(topay_ctx* ctx, int* interrupted /* batch */);
 /* The wall-clock knob of a planning call (max_replan_time, agent_benchmark_tables.yaml:6; the 1.0 s cap of the ALM loop,
